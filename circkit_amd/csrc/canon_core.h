@@ -1,0 +1,457 @@
+// canon_core.h -- one wavefront canonicalizes one circular record.
+//
+// Replaces, per record (reference = Benjamin-Lee/circkit):
+//   lib/src/canonicalize.rs:5-36   lmsr_index  -> find_min_rot()  (smallest minimal-rotation index)
+//   lib/src/canonicalize.rs:41-47  lmsr        -> emit()          (rotation is materialised only once)
+//   lib/src/canonicalize.rs:54-63  canonicalize -> canon_record() (both strands, lexicographic select)
+//   bio 1.3.1 alphabets::dna::revcomp (call site lib/src/canonicalize.rs:56) -> build_*() reverse strand
+//
+// Method (not the reference's sequential Duval loop, which is a ~2n-long dependent chain):
+//   1. Each strand is re-coded order-preservingly and packed big-endian into 32-bit words in LDS
+//      (2 bits/symbol for pure ACGT, 4 bits for the CLI alphabet {-,A,C,G,N,T}, 8 bits for anything
+//      else), followed by two words of periodic extension so no window ever has to wrap.
+//   2. Candidate elimination: every start position's first 32 bits form a key; each lane scans the
+//      32/BITS positions of its word with v_alignbit + v_min, a wave-wide min gives the smallest key M.
+//      For non-repetitive DNA exactly one position owns M -> that is the answer.
+//   3. Otherwise (repeats, low complexity, tiny alphabets): positions whose key == M form a candidate
+//      bitmask; a two-pointer duel over the candidates, each duel a wave-parallel longest-common-prefix
+//      (64 words per step), eliminates whole runs at once and also yields the period, so the SMALLEST
+//      minimal index is returned (the contract pinned by lib/src/canonicalize.rs:154-164,218-221).
+//   4. The two strands' minimal rotations are compared with the same wave-parallel LCP; the winner is
+//      decoded back to bytes straight from the packed words and stored with 16-byte lanes.
+#pragma once
+#include "wave_prims.h"
+
+namespace ck {
+
+struct CanonArgs {
+    const uint8_t* bytes;        // CSR payload (already normalized by the host packer)
+    const uint64_t* offsets;     // [n_records + 1]
+    uint64_t n_records;
+    uint8_t* out_bytes;          // nullable; same offsets as the input
+    uint32_t* out_index;         // nullable
+    uint8_t* out_strand;         // nullable
+    uint64_t* out_hash;          // nullable; XXH3-64 of the canonical bytes
+    const uint32_t* list;        // nullable: record ids to process (a deferred list of a previous tier)
+    const uint32_t* list_count;  // number of entries in `list` (device memory)
+    uint32_t* defer_list;        // nullable: records that do not fit this tier's LDS slice go here
+    uint32_t* defer_count;
+    uint32_t* status;            // [0] = number of records no tier could take
+    const uint8_t* comp_lut;     // 256-entry complement table (bio 1.3.1 semantics)
+    uint32_t slice_dw;           // LDS dwords available to one wave
+};
+
+struct RotResult { uint32_t idx; uint32_t period; };
+struct Lcp { uint32_t k; int cmp; };
+
+// ------------------------------------------------------------------------------------------------
+// packed-word helpers
+// ------------------------------------------------------------------------------------------------
+// The 32/BITS symbols that start at cyclic symbol position p (0 <= p < 2n), first symbol in the top bits.
+template <int BITS>
+CK_DEV uint32_t sym_word(const uint32_t* E, uint32_t p, uint32_t n)
+{
+    constexpr uint32_t S = 32 / BITS;
+    p = p >= n ? p - n : p;
+    uint32_t w = p / S, sh = (p % S) * BITS;
+    return funnel(E[w], E[w + 1], sh);
+}
+
+// min over the S keys that start inside word `cur` (next word `nxt`)
+template <int BITS>
+CK_DEV uint32_t word_min_key(uint32_t cur, uint32_t nxt)
+{
+    constexpr int S = 32 / BITS;
+    uint32_t m = cur;
+#pragma unroll
+    for (int b = 1; b < S; ++b) {
+        uint32_t k = funnel(cur, nxt, b * BITS);
+        m = k < m ? k : m;
+    }
+    return m;
+}
+
+// bit b set iff the key starting at symbol b of word `cur` equals M
+template <int BITS>
+CK_DEV uint32_t word_eq_mask(uint32_t cur, uint32_t nxt, uint32_t M)
+{
+    constexpr int S = 32 / BITS;
+    uint32_t m = (cur == M) ? 1u : 0u;
+#pragma unroll
+    for (int b = 1; b < S; ++b) m |= (funnel(cur, nxt, b * BITS) == M ? 1u : 0u) << b;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// byte -> code conversion with v_perm_b32 as an 8-entry LUT.
+// Index h = (c >> 1) & 7 separates the CLI alphabet: A->0 C->1 T->2 G->3 '-'->6 N->7.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t HASH_MASK = 0x07070707u;
+constexpr uint32_t CHK2_LO = 0x47544341u;  // h0..3 -> 'A','C','T','G'
+constexpr uint32_t CHK4_HI = 0x4E2D0000u;  // h6 -> '-', h7 -> 'N'
+
+// 2-bit codes A0 C1 G2 T3.  Forward: first byte -> most significant.
+CK_DEV uint32_t pack2_fwd(u32x4 v, uint32_t& bad)
+{
+    uint32_t d[4] = { v.x, v.y, v.z, v.w }, u[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t sel = (d[k] >> 1) & HASH_MASK;
+        uint32_t code = perm(0u, 0x02030100u, sel);      // A0 C1 T3 G2 at bits 0-1 of each byte
+        bad |= perm(0u, CHK2_LO, sel) ^ d[k];
+        uint32_t t = code | (code << 10);
+        u[k] = t | (t << 20);                             // top byte = b0 b1 b2 b3 (2 bits each)
+    }
+    return perm(u[0], u[1], 0x07030c0cu) | perm(u[2], u[3], 0x0c0c0703u);
+}
+// Reverse complement of 16 bytes: last byte first, complemented (T0.. -> A3 etc.).
+CK_DEV uint32_t pack2_rc(u32x4 v)
+{
+    uint32_t d[4] = { v.x, v.y, v.z, v.w }, u[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t sel = (d[k] >> 1) & HASH_MASK;
+        uint32_t code = perm(0u, 0x400080C0u, sel);      // comp code << 6: A->3 C->2 T->0 G->1
+        uint32_t t = code | (code << 6);
+        u[k] = t | (t << 12);                             // top byte = b3 b2 b1 b0
+    }
+    return perm(u[3], u[2], 0x07030c0cu) | perm(u[1], u[0], 0x0c0c0703u);
+}
+// 4-bit codes: '-'0 A1 C2 G3 N4 T5.  8 bytes (two dwords) per packed word.
+CK_DEV uint32_t pack4_fwd(uint32_t d0, uint32_t d1, uint32_t& bad)
+{
+    uint32_t s0 = (d0 >> 1) & HASH_MASK, s1 = (d1 >> 1) & HASH_MASK;
+    uint32_t c0 = perm(0x04000000u, 0x03050201u, s0), c1 = perm(0x04000000u, 0x03050201u, s1);
+    bad |= (perm(CHK4_HI, CHK2_LO, s0) ^ d0) | (perm(CHK4_HI, CHK2_LO, s1) ^ d1);
+    uint32_t t0 = c0 | (c0 << 12), t1 = c1 | (c1 << 12);  // byte1 = [b0 b1], byte3 = [b2 b3]
+    return perm(t0, t1, 0x05070103u);
+}
+CK_DEV uint32_t pack4_rc(uint32_t d0, uint32_t d1)
+{
+    uint32_t s0 = (d0 >> 1) & HASH_MASK, s1 = (d1 >> 1) & HASH_MASK;
+    // comp rank << 4: A->T(5) C->G(3) T->A(1) G->C(2) '-'->0 N->4
+    uint32_t c0 = perm(0x40000000u, 0x20103050u, s0), c1 = perm(0x40000000u, 0x20103050u, s1);
+    uint32_t t0 = c0 | (c0 << 4), t1 = c1 | (c1 << 4);    // byte3 = [b3 b2], byte1 = [b1 b0]
+    return perm(t0, t1, 0x03010705u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// strand builders.  Ef / Er receive nwv + 2 words each.  Return true when every byte was in the
+// alphabet of the mode.
+// ------------------------------------------------------------------------------------------------
+template <int BITS>
+CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Er)
+{
+    constexpr uint32_t S = 32 / BITS;           // bytes consumed per packed word
+    const uint32_t lane = lane_id();
+    const uint32_t nwf = n / S, r = n % S, nwv = nwf + (r ? 1u : 0u);
+    uint32_t bad = 0;
+    for (uint32_t w = lane; w < nwv; w += 64) {
+        const bool tail = w >= nwf;
+        // tail words read the last / first S bytes of the record (in bounds: n >= 3S) and are shifted up
+        const uint32_t fa = tail ? n - S : w * S;
+        const uint32_t ra = tail ? 0u : n - S * (w + 1);
+        const uint32_t sh = tail ? (S - r) * BITS : 0u;
+        uint32_t f, c;
+        if (BITS == 2) {
+            f = pack2_fwd(load16(src + fa), bad);
+            c = pack2_rc(load16(src + ra));
+        } else {
+            f = pack4_fwd(load4(src + fa), load4(src + fa + 4), bad);
+            c = pack4_rc(load4(src + ra), load4(src + ra + 4));
+        }
+        Ef[w] = f << sh;
+        Er[w] = c << sh;
+    }
+    const bool ok = ballot(bad != 0) == 0;
+    wave_sync();
+    // periodic extension: E[nwf] gets the head symbols behind the r tail symbols; E[nwv], E[nwv+1] follow.
+    if (lane < 3) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t* E = s ? Er : Ef;
+            if (lane == 0) {
+                if (r) E[nwf] = E[nwf] | (E[0] >> (r * BITS));
+            } else {
+                const uint32_t e = lane - 1;
+                E[nwv + e] = r ? funnel(E[e], E[e + 1], (S - r) * BITS) : E[e];
+            }
+        }
+    }
+    wave_sync();
+    return ok;
+}
+
+// 8-bit mode: any bytes, any n >= 1 (also the path for records shorter than 3 packed words).
+CK_DEV void build_bytes(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Er, const uint8_t* comp)
+{
+    const uint32_t nwv = (n + 3) / 4;
+    for (uint32_t w = lane_id(); w < nwv + 2; w += 64) {
+        uint32_t f = 0, c = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) {
+            const uint32_t x = (4 * w + b) % n;
+            f = (f << 8) | src[x];
+            c = (c << 8) | comp[src[n - 1 - x]];
+        }
+        Ef[w] = f;
+        Er[w] = c;
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-parallel longest common prefix of rotation i of A and rotation j of B (both length n)
+// ------------------------------------------------------------------------------------------------
+template <int BITS>
+CK_DEV Lcp lcp_rot(const uint32_t* A, const uint32_t* B, uint32_t i, uint32_t j, uint32_t n)
+{
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t lane = lane_id();
+    for (uint32_t base = 0; base < n; base += 64 * S) {
+        const uint32_t off = base + lane * S;
+        uint32_t a = 0, b = 0;
+        if (off < n) {
+            a = sym_word<BITS>(A, i + off, n);
+            b = sym_word<BITS>(B, j + off, n);
+        }
+        const uint32_t d = a ^ b;
+        const uint64_t bal = ballot(d != 0);
+        if (bal) {
+            const uint32_t l = (uint32_t)ffs64(bal);
+            const uint32_t dd = readlane(d, l), aa = readlane(a, l), bb = readlane(b, l);
+            const uint32_t k = base + l * S + (uint32_t)clz32(dd) / BITS;
+            if (k >= n) return Lcp{ n, 0 };
+            return Lcp{ k, aa > bb ? 1 : -1 };
+        }
+    }
+    return Lcp{ n, 0 };
+}
+
+// lowest set bit >= x in the candidate bitmask (n bits, no bits >= n set); n if none
+CK_DEV uint32_t next_cand(const uint32_t* bm, uint32_t x, uint32_t n)
+{
+    if (x >= n) return n;
+    const uint32_t nbm = (n + 31) / 32, first = x / 32, lane = lane_id();
+    for (uint32_t wb = first; wb < nbm; wb += 64) {
+        const uint32_t idx = wb + lane;
+        uint32_t v = idx < nbm ? bm[idx] : 0u;
+        if (idx == first) v &= ~0u << (x % 32);
+        const uint64_t bal = ballot(v != 0);
+        if (bal) {
+            const uint32_t l = (uint32_t)ffs64(bal);
+            return (wb + l) * 32 + (uint32_t)ffs32(readlane(v, l));
+        }
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// smallest index of the lexicographically minimal rotation + the rotation period
+// ------------------------------------------------------------------------------------------------
+template <int BITS>
+CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
+{
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t lane = lane_id();
+    const uint32_t nwv = (n + S - 1) / S;
+
+    // dense scan: per-lane minimum key, which word owns it, and how many of the lane's words tie
+    uint32_t best = ~0u, bestw = 0, ties = 0;
+    for (uint32_t w = lane; w < nwv; w += 64) {
+        const uint32_t m = word_min_key<BITS>(E[w], E[w + 1]);
+        if (m < best || ties == 0) { best = m; bestw = w; ties = 1; }
+        else if (m == best) ++ties;
+    }
+    const uint32_t M = wave_min_u32(best);
+    const uint64_t hm = ballot(ties != 0 && best == M);
+
+    // fast path: at most two words hold M (the second is normally the duplicate of word 0's positions
+    // that sits behind the record end in the last word) and exactly one valid position owns it.
+    if (popc64(hm) <= 2) {
+        uint32_t cnt = 0, pos = 0;
+        bool multi = false;
+        uint64_t mm = hm;
+        while (mm) {
+            const uint32_t l = (uint32_t)ffs64(mm);
+            mm &= mm - 1;
+            const uint32_t tl = readlane(ties, l), wl = readlane(bestw, l);
+            if (tl != 1) { multi = true; break; }
+            const uint32_t b = lane % S;
+            const uint32_t k = funnel(E[wl], E[wl + 1], b * BITS);
+            const uint64_t pm = ballot(lane < S && k == M && wl * S + b < n);
+            cnt += (uint32_t)popc64(pm);
+            if (pm) pos = wl * S + (uint32_t)ffs64(pm);
+        }
+        if (!multi && cnt == 1) return RotResult{ pos, n };
+    }
+
+    // general path.  1: candidate bitmask = positions whose key equals M
+    const uint32_t nbm = (n + 31) / 32;
+    for (uint32_t t = lane; t < nbm; t += 64) bm[t] = 0;
+    wave_sync();
+    for (uint32_t w = lane; w < nwv; w += 64) {
+        uint32_t m = word_eq_mask<BITS>(E[w], E[w + 1], M);
+        const uint32_t valid = n - w * S;
+        if (valid < S) m &= (1u << valid) - 1u;
+        const uint32_t p = w * S;
+#ifndef CK_EMU
+        if (m) atomicOr(&bm[p / 32], m << (p % 32));
+#else
+        if (m) bm[p / 32] |= m << (p % 32);
+#endif
+    }
+    wave_sync();
+    // 2: duel.  Invariant: alive candidates = {i} U {candidates >= j}; a minimal start is never killed.
+    uint32_t i = next_cand(bm, 0, n);
+    uint32_t j = next_cand(bm, i + 1, n);
+    uint32_t period = n;
+    while (j < n) {
+        const Lcp c = lcp_rot<BITS>(E, E, i, j, n);
+        if (c.k >= n) { period = j - i; break; }       // equal rotations: i is the smallest minimal start
+        if (c.cmp > 0) {                                // rotation j is smaller: i .. i+k are dead
+            const uint32_t ni = (i + c.k + 1 <= j) ? j : next_cand(bm, i + c.k + 1, n);
+            if (ni >= n) break;                         // unreachable: a minimal start always survives
+            i = ni;
+            j = next_cand(bm, i + 1, n);
+        } else {                                        // rotation i is smaller: j .. j+k are dead
+            j = next_cand(bm, j + c.k + 1, n);
+        }
+    }
+    return RotResult{ i, period };
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode the winner back to bytes and store it
+// ------------------------------------------------------------------------------------------------
+CK_DEV void store_bytes(uint8_t* p, u32x4 v, uint32_t nb)   // nb = 1..16 bytes of v
+{
+    if (nb >= 16) { store16(p, v); return; }
+    if (nb & 8) { store8(p, v.x, v.y); p += 8; v.x = v.z; v.y = v.w; }
+    if (nb & 4) { store4(p, v.x); p += 4; v.x = v.y; }
+    if (nb & 2) { p[0] = (uint8_t)v.x; p[1] = (uint8_t)(v.x >> 8); p += 2; v.x >>= 16; }
+    if (nb & 1) { p[0] = (uint8_t)v.x; }
+}
+
+// 16 symbols (2 bits each, first in the top bits) -> 16 ASCII bytes
+CK_DEV u32x4 decode2(uint32_t v)
+{
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = (v >> (24 - 8 * k)) & 0xFFu;
+        const uint32_t t = x | (x << 10);
+        const uint32_t z = t | (t << 20);
+        o[k] = perm(0u, 0x54474341u, (z >> 6) & 0x03030303u);   // 0..3 -> 'A','C','G','T'
+    }
+    return u32x4{ o[0], o[1], o[2], o[3] };
+}
+// 8 symbols (4 bits each) -> 8 ASCII bytes in (lo, hi)
+CK_DEV void decode4(uint32_t v, uint32_t& lo, uint32_t& hi)
+{
+    const uint32_t a = perm(0u, v, 0x02020303u), b = perm(0u, v, 0x00000101u);
+    const uint32_t sa = ((a >> 4) & 0x000F000Fu) | (a & 0x0F000F00u);
+    const uint32_t sb = ((b >> 4) & 0x000F000Fu) | (b & 0x0F000F00u);
+    lo = perm(0x0000544Eu, 0x4743412Du, sa);                       // 0..5 -> '-','A','C','G','N','T'
+    hi = perm(0x0000544Eu, 0x4743412Du, sb);
+}
+
+template <int BITS>
+CK_DEV void emit(const uint32_t* E, uint32_t idx, uint32_t n, uint8_t* out)
+{
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t nwv = (n + S - 1) / S;
+    for (uint32_t w = lane_id(); w < nwv; w += 64) {
+        const uint32_t v = sym_word<BITS>(E, idx + w * S, n);
+        const uint32_t left = n - w * S;
+        u32x4 o{ 0, 0, 0, 0 };
+        if (BITS == 2) {
+            o = decode2(v);
+        } else if (BITS == 4) {
+            decode4(v, o.x, o.y);
+        } else {
+            o.x = perm(0u, v, 0x00010203u);
+        }
+        store_bytes(out + w * S, o, left < S ? left : S);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one record, one mode.  Returns false if the record's bytes are outside the mode's alphabet.
+// ------------------------------------------------------------------------------------------------
+template <int BITS>
+CK_DEV uint32_t need_dw(uint32_t n)
+{
+    constexpr uint32_t S = 32 / BITS;
+    return 2 * ((n + S - 1) / S + 2) + (n + 31) / 32 + 1;
+}
+
+template <int BITS>
+CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* src, uint64_t off, uint32_t n,
+                              uint32_t* lds)
+{
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t nwv = (n + S - 1) / S;
+    uint32_t* Ef = lds;
+    uint32_t* Er = lds + (nwv + 2);
+    uint32_t* bm = lds + 2 * (nwv + 2);
+    if (BITS == 8) {
+        build_bytes(src, n, Ef, Er, a.comp_lut);
+    } else {
+        if (!build_packed<BITS>(src, n, Ef, Er)) return false;
+    }
+    const RotResult f = find_min_rot<BITS>(Ef, n, bm);
+    const RotResult r = find_min_rot<BITS>(Er, n, bm);
+    // lib/src/canonicalize.rs:58-62: forward only if strictly smaller
+    const Lcp c = lcp_rot<BITS>(Ef, Er, f.idx, r.idx, n);
+    const bool fwd = c.cmp < 0;
+    if (a.out_bytes) emit<BITS>(fwd ? Ef : Er, fwd ? f.idx : r.idx, n, a.out_bytes + off);
+    if (lane_id() == 0) {
+        // index as the reference would see it: lmsr_index(s) for the forward strand,
+        // lmsr_index(revcomp(lmsr(s))) for the reverse strand (rotation by f.idx, modulo the period)
+        if (a.out_index) a.out_index[rec] = fwd ? f.idx : (r.idx + f.idx) % f.period;
+        if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+    }
+    return true;
+}
+
+// Processes one record; returns false if it does not fit this tier's LDS slice.
+CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds)
+{
+    const uint64_t off = a.offsets[rec];
+    const uint32_t n = (uint32_t)(a.offsets[rec + 1] - off);
+    const uint8_t* src = a.bytes + off;
+    if (n == 0) {
+        if (lane_id() == 0) {
+            if (a.out_index) a.out_index[rec] = 0;
+            if (a.out_strand) a.out_strand[rec] = 1;
+        }
+        return true;
+    }
+    if (n >= 48) {
+        if (need_dw<2>(n) > a.slice_dw) return false;
+        if (canon_record_mode<2>(a, rec, src, off, n, lds)) return true;
+        if (need_dw<4>(n) > a.slice_dw) return false;
+        if (canon_record_mode<4>(a, rec, src, off, n, lds)) return true;
+    }
+    if (need_dw<8>(n) > a.slice_dw) return false;
+    canon_record_mode<8>(a, rec, src, off, n, lds);
+    return true;
+}
+
+// grid-stride loop of one wave over the work list
+CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t wave_id, uint32_t n_waves)
+{
+    const uint64_t total = a.list ? (uint64_t)a.list_count[0] : a.n_records;
+    for (uint64_t t = wave_id; t < total; t += n_waves) {
+        const uint64_t rec = a.list ? (uint64_t)a.list[t] : t;
+        const bool done = canon_record(a, rec, lds);
+        if (!done && lane_id() == 0) {
+            if (a.defer_list) a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
+            else atomic_add_u32(a.status, 1u);
+        }
+        wave_sync();
+    }
+}
+
+}  // namespace ck

@@ -1,0 +1,185 @@
+// wave_prims.h -- the handful of wavefront-level primitives the circkit kernels are written against.
+//
+// Device build (hipcc, gfx950): thin wrappers over CDNA4 intrinsics (64-lane ballot, ds_bpermute,
+// v_perm_b32, v_alignbit_b32, DPP-based reductions).
+// CK_EMU build (g++, tests only): the same kernel source runs as 64 cooperatively scheduled fibers
+// per wave (tests/emu/), so kernel logic can be checked against the oracle on a machine without a
+// GPU.  The emulator is test infrastructure: it is never linked into libcirckit_hip.so.
+//
+// Discipline the kernels keep (and the emulator asserts): every collective (ballot / shfl / readlane /
+// wave_min / wave_sync) is executed by all 64 lanes in wave-uniform control flow.
+#pragma once
+#include <stdint.h>
+
+#ifndef CK_EMU
+// ================================================================================================
+// gfx950 device build
+// ================================================================================================
+#include <hip/hip_runtime.h>
+#define CK_DEV __device__ __forceinline__
+#define CK_DEV_NOINLINE __device__ __noinline__
+
+namespace ck {
+
+CK_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+CK_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+CK_DEV uint32_t shfl(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+CK_DEV uint32_t readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+CK_DEV uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+CK_DEV uint64_t uniform64(uint64_t v)
+{
+    return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v);
+}
+// LDS traffic of one wave is issued and serviced in order; this only stops the compiler from
+// moving LDS accesses across the point (no instruction besides a possible s_waitcnt).
+CK_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+CK_DEV uint32_t wave_min_u32(uint32_t v)
+{
+    // 6-step butterfly over 64 lanes; result in every lane.
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ m) << 2), (int)v);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+CK_DEV uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ m) << 2), (int)(uint32_t)v);
+        uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ m) << 2), (int)(uint32_t)(v >> 32));
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+CK_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
+// funnel: the 32 bits starting `sh` bits (0..31) into the 64-bit value hi:lo, counted from the top
+CK_DEV uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;   // v_alignbit_b32: ({hi,lo} >> n)[31:0]
+}
+CK_DEV uint32_t bitrev(uint32_t v) { return __builtin_bitreverse32(v); }
+CK_DEV int ffs64(uint64_t v) { return __builtin_ctzll(v); }   // v != 0
+CK_DEV int ffs32(uint32_t v) { return __builtin_ctz(v); }     // v != 0
+CK_DEV int clz32(uint32_t v) { return __builtin_clz(v); }     // v != 0
+CK_DEV int popc64(uint64_t v) { return __builtin_popcountll(v); }
+CK_DEV int popc32(uint32_t v) { return __builtin_popcount(v); }
+
+struct u32x4 { uint32_t x, y, z, w; };
+// Global memory on gfx950 runs in unaligned access mode: a dwordx4 load/store may start at any byte.
+CK_DEV u32x4 load16(const uint8_t* p)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(1)));
+    v4 v = *reinterpret_cast<const v4*>(p);
+    return u32x4{ v.x, v.y, v.z, v.w };
+}
+CK_DEV void store16(uint8_t* p, u32x4 v)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(1)));
+    v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *reinterpret_cast<v4*>(p) = t;
+}
+CK_DEV void store8(uint8_t* p, uint32_t a, uint32_t b)
+{
+    typedef uint32_t v2 __attribute__((ext_vector_type(2), aligned(1)));
+    v2 t; t.x = a; t.y = b;
+    *reinterpret_cast<v2*>(p) = t;
+}
+CK_DEV void store4(uint8_t* p, uint32_t a)
+{
+    typedef uint32_t v1 __attribute__((aligned(1)));
+    *reinterpret_cast<v1*>(p) = a;
+}
+CK_DEV uint32_t load4(const uint8_t* p)
+{
+    typedef uint32_t v1 __attribute__((aligned(1)));
+    return *reinterpret_cast<const v1*>(p);
+}
+CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+
+}  // namespace ck
+
+#else
+// ================================================================================================
+// CPU fiber emulation (tests only)
+// ================================================================================================
+#include <string.h>
+#define CK_DEV static inline
+#define CK_DEV_NOINLINE static
+
+namespace ck {
+
+namespace emu {
+uint32_t cur_lane();
+void gather(uint64_t v, uint64_t out[64]);   // collective all-gather over the 64 lanes of the wave
+}
+
+CK_DEV uint32_t lane_id() { return emu::cur_lane(); }
+CK_DEV uint64_t ballot(bool p)
+{
+    uint64_t all[64]; emu::gather(p ? 1 : 0, all);
+    uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (all[i] & 1) << i;
+    return m;
+}
+CK_DEV uint32_t shfl(uint32_t v, uint32_t src) { uint64_t all[64]; emu::gather(v, all); return (uint32_t)all[src & 63]; }
+CK_DEV uint32_t readlane(uint32_t v, uint32_t l) { uint64_t all[64]; emu::gather(v, all); return (uint32_t)all[l & 63]; }
+CK_DEV uint32_t uniform(uint32_t v) { uint64_t all[64]; emu::gather(v, all); return (uint32_t)all[0]; }
+CK_DEV uint64_t uniform64(uint64_t v) { uint64_t all[64]; emu::gather(v, all); return all[0]; }
+CK_DEV void wave_sync() { uint64_t all[64]; emu::gather(0, all); }
+CK_DEV uint32_t wave_min_u32(uint32_t v)
+{
+    uint64_t all[64]; emu::gather(v, all);
+    uint32_t m = ~0u; for (int i = 0; i < 64; ++i) m = (uint32_t)all[i] < m ? (uint32_t)all[i] : m;
+    return m;
+}
+CK_DEV uint64_t wave_sum_u64(uint64_t v)
+{
+    uint64_t all[64]; emu::gather(v, all);
+    uint64_t s = 0; for (int i = 0; i < 64; ++i) s += all[i];
+    return s;
+}
+CK_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+    uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        uint32_t k = (sel >> (8 * i)) & 0xFF, b;
+        if (k <= 7) b = (uint32_t)(src >> (8 * k)) & 0xFF;
+        else if (k == 12) b = 0;            // v_perm_b32: 0x0c -> 0x00
+        else if (k >= 13) b = 0xFF;         //             >= 0x0d -> 0xff
+        else b = 0;                         // 8..11 (sign replication) are never used by the kernels
+        r |= b << (8 * i);
+    }
+    return r;
+}
+CK_DEV uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+    return sh ? (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (32u - sh)) : hi;
+}
+CK_DEV uint32_t bitrev(uint32_t v)
+{
+    uint32_t r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+CK_DEV int ffs64(uint64_t v) { return __builtin_ctzll(v); }
+CK_DEV int ffs32(uint32_t v) { return __builtin_ctz(v); }
+CK_DEV int clz32(uint32_t v) { return __builtin_clz(v); }
+CK_DEV int popc64(uint64_t v) { return __builtin_popcountll(v); }
+CK_DEV int popc32(uint32_t v) { return __builtin_popcount(v); }
+
+struct u32x4 { uint32_t x, y, z, w; };
+CK_DEV u32x4 load16(const uint8_t* p) { u32x4 v; memcpy(&v, p, 16); return v; }
+CK_DEV void store16(uint8_t* p, u32x4 v) { memcpy(p, &v, 16); }
+CK_DEV void store8(uint8_t* p, uint32_t a, uint32_t b) { memcpy(p, &a, 4); memcpy(p + 4, &b, 4); }
+CK_DEV void store4(uint8_t* p, uint32_t a) { memcpy(p, &a, 4); }
+CK_DEV uint32_t load4(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+
+}  // namespace ck
+#endif

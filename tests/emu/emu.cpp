@@ -1,0 +1,125 @@
+// CPU fiber emulator for the wave-level kernels (TEST INFRASTRUCTURE ONLY, never linked into the product).
+// Compiles circkit_amd/csrc/canon_core.h with CK_EMU: each wavefront is 64 ucontext fibers scheduled
+// round-robin; every collective primitive is a rendezvous of all 64 fibers (a lane that skips a
+// collective deadlocks the wave, which is reported -- the same discipline the GPU build relies on).
+#define CK_EMU 1
+#include <ucontext.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../circkit_amd/csrc/wave_prims.h"
+
+namespace ck { namespace emu {
+struct WaveState {
+    ucontext_t main_ctx, ctx[64];
+    std::vector<char> stacks;
+    int cur = 0;
+    uint64_t buf[2][64];
+    int cnt[2] = {0, 0};
+    uint32_t complete[2] = {0xFFFFFFFFu, 0xFFFFFFFEu};
+    uint32_t gen[64];
+    bool done[64];
+    void (*body)(void*) = nullptr;
+    void* arg = nullptr;
+};
+static WaveState* W = nullptr;
+
+uint32_t cur_lane() { return (uint32_t)W->cur; }
+
+static void yield_next()
+{
+    int from = W->cur, nx = from;
+    for (int t = 0; t < 64; ++t) {
+        nx = (nx + 1) & 63;
+        if (!W->done[nx]) break;
+    }
+    if (nx == from || W->done[nx]) {
+        fprintf(stderr, "emu: wave deadlock -- lane %d waits in a collective the other lanes never reach\n", from);
+        abort();
+    }
+    W->cur = nx;
+    swapcontext(&W->ctx[from], &W->ctx[nx]);
+}
+
+void gather(uint64_t v, uint64_t out[64])
+{
+    const int l = W->cur;
+    const uint32_t g = W->gen[l]++;
+    const int s = g & 1;
+    W->buf[s][l] = v;
+    if (++W->cnt[s] == 64) { W->complete[s] = g; W->cnt[s] = 0; }
+    while (W->complete[s] != g) yield_next();
+    for (int i = 0; i < 64; ++i) out[i] = W->buf[s][i];
+}
+
+static void trampoline()
+{
+    const int l = W->cur;
+    W->body(W->arg);
+    W->done[l] = true;
+    // hand over to the next unfinished lane, or back to main when all are done
+    for (int t = 1; t <= 64; ++t) {
+        int nx = (l + t) & 63;
+        if (!W->done[nx]) { W->cur = nx; setcontext(&W->ctx[nx]); }
+    }
+    setcontext(&W->main_ctx);
+}
+
+void run_wave(void (*body)(void*), void* arg)
+{
+    static WaveState st;
+    W = &st;
+    const size_t STK = 256 * 1024;
+    if (st.stacks.empty()) st.stacks.resize(64 * STK);
+    st.body = body; st.arg = arg;
+    st.cnt[0] = st.cnt[1] = 0;
+    st.complete[0] = 0xFFFFFFFFu; st.complete[1] = 0xFFFFFFFEu;
+    for (int i = 0; i < 64; ++i) {
+        st.gen[i] = 0; st.done[i] = false;
+        getcontext(&st.ctx[i]);
+        st.ctx[i].uc_stack.ss_sp = st.stacks.data() + i * STK;
+        st.ctx[i].uc_stack.ss_size = STK;
+        st.ctx[i].uc_link = &st.main_ctx;
+        makecontext(&st.ctx[i], (void (*)())trampoline, 0);
+    }
+    st.cur = 0;
+    swapcontext(&st.main_ctx, &st.ctx[0]);
+    for (int i = 0; i < 64; ++i)
+        if (!st.done[i]) { fprintf(stderr, "emu: lane %d did not finish\n", i); abort(); }
+}
+}}  // namespace ck::emu
+
+#include "../../circkit_amd/csrc/canon_core.h"
+
+namespace {
+struct Launch { ck::CanonArgs a; uint32_t* lds; uint32_t wave_id, n_waves; };
+void wave_body(void* p)
+{
+    Launch* L = (Launch*)p;
+    ck::canon_wave_loop(L->a, L->lds, L->wave_id, L->n_waves);
+}
+}
+
+extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
+                                      uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
+                                      uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
+                                      uint32_t* n_deferred)
+{
+    uint8_t comp[256];
+    for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
+    const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
+    for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
+    std::vector<uint32_t> lds(slice_dw + 16), deferred(n_records + 1);
+    uint32_t defer_count = 0, status = 0;
+    Launch L;
+    L.a = ck::CanonArgs{ bytes, offsets, n_records, out_bytes, out_index, out_strand, out_hash,
+                         nullptr, nullptr, deferred.data(), &defer_count, &status, comp, slice_dw };
+    L.lds = lds.data();
+    L.n_waves = n_waves;
+    for (uint32_t w = 0; w < n_waves; ++w) {
+        L.wave_id = w;
+        ck::emu::run_wave(wave_body, &L);
+    }
+    if (n_deferred) *n_deferred = defer_count;
+    return (int)status;
+}

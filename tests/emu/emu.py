@@ -1,0 +1,44 @@
+"""Loads the CPU fiber emulator of the wave kernels (tests only)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcanon_emu.so")
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "circkit_amd", "csrc")
+
+
+def build():
+    srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", _SO,
+                               os.path.join(_HERE, "emu.cpp")])
+    return _SO
+
+
+_lib = None
+
+
+def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False):
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.emu_canonicalize_batch.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4 + \
+            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    pad = np.zeros(len(data) + 64, dtype=np.uint8)   # same tail padding the device buffers have
+    pad[:len(data)] = data
+    out = np.full(len(data) + 64, 0x3F, dtype=np.uint8)
+    idx = np.full(max(n, 1), 0xFFFFFFFF, dtype=np.uint32)
+    strand = np.full(max(n, 1), 0xFF, dtype=np.uint8)
+    hs = np.zeros(max(n, 1), dtype=np.uint64)
+    ndef = ctypes.c_uint32(0)
+    st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data, idx.ctypes.data,
+                                     strand.ctypes.data, hs.ctypes.data if want_hash else None,
+                                     slice_dw, n_waves, ctypes.byref(ndef))
+    assert (out[len(data):] == 0x3F).all(), "kernel wrote past the end of the output buffer"
+    return out[:len(data)], idx[:n], strand[:n], hs[:n], st, ndef.value

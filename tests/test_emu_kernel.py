@@ -1,0 +1,64 @@
+"""Runs the wave-level kernel source (circkit_amd/csrc/canon_core.h) through the CPU fiber emulator and
+checks it against the oracle.  This validates the kernel LOGIC on a machine without a GPU; the GPU parity
+tests (test_gpu_parity.py, -m gpu) check the gfx950 build itself."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import seqsets
+from tests.emu import emu
+
+
+def check(seqs, **kw):
+    data, offs = seqsets.pack(seqs)
+    out, idx, strand, _, status, ndef = emu.canonicalize_batch(data, offs, **kw)
+    assert status == 0
+    deferred = 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        exp, est, eidx = seqsets.expected(O, s)
+        if strand[i] == 0xFF and len(s):      # deferred to a bigger LDS tier: untouched
+            deferred += 1
+            continue
+        assert out[a:b].tobytes() == exp, (i, len(s), s[:80])
+        assert int(strand[i]) == est, (i, s[:80])
+        if len(s):
+            assert int(idx[i]) == eidx, (i, s[:80])
+    assert deferred == ndef
+    return ndef
+
+
+def test_adversarial_set():
+    assert check(seqsets.adversarial(), slice_dw=4096) == 0
+
+
+def test_random_acgt_1kb():
+    check(seqsets.random_mixed(21, 150, 1000, 1000))
+
+
+def test_random_lengths_all_alphabets():
+    check(seqsets.random_mixed(22, 300, 1, 700))
+    check(seqsets.random_mixed(23, 200, 1, 700, b"ACGTN"))
+    check(seqsets.random_mixed(24, 200, 1, 500, b"-ACGNT"))
+    check(seqsets.random_mixed(25, 100, 1, 300, bytes(range(0x21, 0x7F))))
+    check(seqsets.random_mixed(26, 300, 1, 200, b"AC"))
+    check(seqsets.random_mixed(27, 300, 1, 120, b"A"))
+
+
+def test_long_records_multi_row():
+    check(seqsets.random_mixed(28, 6, 2000, 9000), slice_dw=4096)
+    check(seqsets.random_mixed(29, 4, 1500, 5000, b"ACGTN"), slice_dw=4096)
+
+
+def test_deferral_to_bigger_tier():
+    seqs = seqsets.random_mixed(30, 20, 100, 3000)
+    n = check(seqs, slice_dw=200)
+    assert 0 < n < len(seqs)
+
+
+def test_wave_count_independent():
+    seqs = seqsets.random_mixed(31, 40, 48, 300)
+    data, offs = seqsets.pack(seqs)
+    a = emu.canonicalize_batch(data, offs, n_waves=1)
+    b = emu.canonicalize_batch(data, offs, n_waves=7)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
