@@ -39,7 +39,9 @@ struct CanonArgs {
     uint32_t* status;            // [0] = number of records no tier could take
     const uint8_t* comp_lut;     // 256-entry complement table (bio 1.3.1 semantics)
     uint32_t slice_dw;           // LDS dwords available to one wave
+    uint32_t flags;              // CK_FLAG_*
 };
+constexpr uint32_t CK_FLAG_FWD_ONLY = 1u;   // lmsr(): forward strand only (lib/src/canonicalize.rs:41-47)
 
 struct RotResult { uint32_t idx; uint32_t period; };
 struct Lcp { uint32_t k; int cmp; };
@@ -401,10 +403,13 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
         if (!build_packed<BITS>(src, n, Ef, Er)) return false;
     }
     const RotResult f = find_min_rot<BITS>(Ef, n, bm);
-    const RotResult r = find_min_rot<BITS>(Er, n, bm);
-    // lib/src/canonicalize.rs:58-62: forward only if strictly smaller
-    const Lcp c = lcp_rot<BITS>(Ef, Er, f.idx, r.idx, n);
-    const bool fwd = c.cmp < 0;
+    RotResult r{ 0, n };
+    bool fwd = true;
+    if (!(a.flags & CK_FLAG_FWD_ONLY)) {
+        r = find_min_rot<BITS>(Er, n, bm);
+        // lib/src/canonicalize.rs:58-62: forward only if strictly smaller
+        fwd = lcp_rot<BITS>(Ef, Er, f.idx, r.idx, n).cmp < 0;
+    }
     if (a.out_bytes) emit<BITS>(fwd ? Ef : Er, fwd ? f.idx : r.idx, n, a.out_bytes + off);
     if (lane_id() == 0) {
         // index as the reference would see it: lmsr_index(s) for the forward strand,

@@ -1,0 +1,563 @@
+// circkit_hip.hip -- gfx950 kernels + the C ABI of include/circkit.h.
+// Built by __graft_entry__.build():  hipcc --offload-arch=gfx950 -O3 -shared -fPIC -> libcirckit_hip.so
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/circkit.h"
+#include "canon_core.h"
+#include "xxh3_core.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+// One wavefront per record, WPB wavefronts per workgroup, each with its own LDS slice.  The waves of
+// a workgroup take consecutive records, so a workgroup streams one contiguous span of the CSR payload.
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t wib = ck::uniform(threadIdx.x >> 6);
+    const uint32_t wave = ck::uniform(blockIdx.x * WPB + wib);
+    ck::canon_wave_loop(a, lds + wib * a.slice_dw, wave, gridDim.x * WPB);
+}
+
+// XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).
+__global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
+                                                   uint64_t* out)
+{
+    const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint64_t r = wave; r < n_records; r += n_waves) {
+        const uint64_t off = offsets[r];
+        const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
+        if (ck::lane_id() == 0) out[r] = h;
+    }
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+// 16 bases per thread, 16-byte stores; base g uses bits 2*(g&31) of splitmix64(seed*K + (g>>5)).
+__global__ __launch_bounds__(256) void synth_fill_kernel(uint64_t seed, uint64_t first_base, uint64_t n_bases,
+                                                         uint8_t* out)
+{
+    const uint64_t key = seed * 0xD1342543DE82EF95ULL;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 16;
+    for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n_bases; i += stride) {
+        const uint64_t g0 = first_base + i;
+        uint64_t wi = g0 >> 5, w = splitmix64(key + wi);
+        uint32_t o[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const uint64_t g = g0 + b;
+            if ((g >> 5) != wi) { wi = g >> 5; w = splitmix64(key + wi); }
+            const uint32_t code = (uint32_t)(w >> (2 * (g & 31))) & 3u;
+            o[b >> 2] |= ((0x54474341u >> (8 * code)) & 0xFFu) << (8 * (b & 3));
+        }
+        if (i + 16 <= n_bases) {
+            ck::store16(out + i, ck::u32x4{ o[0], o[1], o[2], o[3] });
+        } else {
+            for (uint64_t b = 0; i + b < n_bases; ++b) out[i + b] = (uint8_t)(o[b >> 2] >> (8 * (b & 3)));
+        }
+    }
+}
+
+__global__ void fixed_offsets_kernel(uint64_t base, uint64_t len, uint64_t n, uint64_t* off)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) off[i] = base + i * len;
+}
+
+// uniq: open-addressing table keyed by the 64-bit hash, value = smallest global record index.
+constexpr uint64_t UNIQ_EMPTY = ~0ull;
+__device__ __forceinline__ uint64_t uniq_slot(uint64_t h, uint64_t mask) { return (h ^ (h >> 29)) & mask; }
+
+__global__ void uniq_insert_kernel(const uint64_t* hash, uint64_t n, uint64_t base, unsigned long long* keys,
+                                   unsigned long long* vals, uint64_t mask, uint32_t* status)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = hash[i];
+        if (h == UNIQ_EMPTY) { atomicMin(&vals[mask + 1], (unsigned long long)(base + i)); continue; }
+        uint64_t s = uniq_slot(h, mask);
+        uint64_t probes = 0;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
+            if (old == UNIQ_EMPTY || old == h) { atomicMin(&vals[s], (unsigned long long)(base + i)); break; }
+            s = (s + 1) & mask;
+            if (++probes > mask) { atomicAdd(status, 1u); break; }   // table full
+        }
+    }
+}
+
+__global__ void uniq_lookup_kernel(const uint64_t* hash, uint64_t n, const unsigned long long* keys,
+                                   const unsigned long long* vals, uint64_t mask, uint64_t* first_seen)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = hash[i];
+        if (h == UNIQ_EMPTY) { first_seen[i] = vals[mask + 1]; continue; }
+        uint64_t s = uniq_slot(h, mask), probes = 0, r = UNIQ_EMPTY;
+        for (;;) {
+            const uint64_t k = keys[s];
+            if (k == h) { r = vals[s]; break; }
+            if (k == UNIQ_EMPTY || ++probes > mask) break;
+            s = (s + 1) & mask;
+        }
+        first_seen[i] = r;
+    }
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long long v)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS tiers (dwords per wave).  A: 4 waves x 4 KiB per workgroup, 8 workgroups per CU.
+// B: one wave with 40 KiB (4 per CU).  C: one wave with the whole 160 KiB CU.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TIER_A_DW = 1024, TIER_B_DW = 10240, TIER_C_DW = 40704;
+constexpr int N_CU = 256;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// ctx
+// ------------------------------------------------------------------------------------------------
+struct circkit_ctx {
+    int device = -1;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+    uint8_t* d_comp = nullptr;
+    uint32_t* d_counters = nullptr;      // [0],[1] deferred counts of tiers A,B; [2] unprocessed; [3] uniq overflow
+    uint32_t* d_list_a = nullptr;        // deferred lists
+    uint32_t* d_list_b = nullptr;
+    uint64_t list_cap = 0;
+    // host-batch staging (grow only)
+    uint8_t *d_in = nullptr, *d_out = nullptr, *d_strand = nullptr;
+    uint64_t* d_off = nullptr; uint32_t* d_idx = nullptr; uint64_t* d_hash = nullptr;
+    uint64_t cap_bytes = 0, cap_rec = 0;
+    // uniq table
+    unsigned long long *d_keys = nullptr, *d_vals = nullptr;
+    uint64_t uniq_mask = 0;
+};
+
+namespace {
+
+int fail(circkit_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define CK_HIP(c, call)                                                                             \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(c, e_ == hipErrorOutOfMemory ? CIRCKIT_ERR_OOM : CIRCKIT_ERR_HIP,           \
+                        "%s failed: %s", #call, hipGetErrorString(e_));                             \
+    } while (0)
+
+int ensure_lists(circkit_ctx* c, uint64_t n)
+{
+    if (n <= c->list_cap) return CIRCKIT_OK;
+    if (c->d_list_a) { (void)hipFree(c->d_list_a); c->d_list_a = nullptr; }
+    if (c->d_list_b) { (void)hipFree(c->d_list_b); c->d_list_b = nullptr; }
+    c->list_cap = 0;
+    CK_HIP(c, hipMalloc(&c->d_list_a, n * sizeof(uint32_t)));
+    CK_HIP(c, hipMalloc(&c->d_list_b, n * sizeof(uint32_t)));
+    c->list_cap = n;
+    return CIRCKIT_OK;
+}
+
+int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out,
+                 uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags)
+{
+    if (n >= (1ull << 32)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^32");
+    CK_HIP(c, hipSetDevice(c->device));
+    if (n == 0) { c->timed = false; return CIRCKIT_OK; }
+    int rc = ensure_lists(c, n);
+    if (rc) return rc;
+    CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(uint32_t), c->stream));
+    CK_HIP(c, hipEventRecord(c->ev0, c->stream));
+    ck::CanonArgs a{};
+    a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
+    a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr;
+    a.comp_lut = c->d_comp; a.status = c->d_counters + 2; a.flags = flags;
+    // tier A over every record
+    a.list = nullptr; a.list_count = nullptr; a.defer_list = c->d_list_a; a.defer_count = c->d_counters + 0;
+    a.slice_dw = TIER_A_DW;
+    {
+        const uint64_t blocks = (n + 3) / 4;
+        const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
+        hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), 4 * TIER_A_DW * 4, c->stream, a);
+    }
+    // tier B over what A deferred, tier C over what B deferred (both exit at once on empty lists)
+    a.list = c->d_list_a; a.list_count = c->d_counters + 0; a.defer_list = c->d_list_b; a.defer_count = c->d_counters + 1;
+    a.slice_dw = TIER_B_DW;
+    hipLaunchKernelGGL(canon_kernel<1>, dim3(N_CU * 4), dim3(64), TIER_B_DW * 4, c->stream, a);
+    a.list = c->d_list_b; a.list_count = c->d_counters + 1; a.defer_list = nullptr; a.defer_count = nullptr;
+    a.slice_dw = TIER_C_DW;
+    hipLaunchKernelGGL(canon_kernel<1>, dim3(N_CU), dim3(64), TIER_C_DW * 4, c->stream, a);
+    if (d_hash) {
+        if (!d_out) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_out_xxh3 currently needs d_out_bytes");
+        const uint64_t blocks = (n + 3) / 4;
+        const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
+        hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash);
+    }
+    CK_HIP(c, hipEventRecord(c->ev1, c->stream));
+    CK_HIP(c, hipGetLastError());
+    c->timed = true;
+    return CIRCKIT_OK;
+}
+
+template <class T>
+int grow(circkit_ctx* c, T*& p, uint64_t want_elems)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+    CK_HIP(c, hipMalloc(&p, want_elems * sizeof(T)));
+    return CIRCKIT_OK;
+}
+
+int ensure_staging(circkit_ctx* c, uint64_t bytes, uint64_t recs)
+{
+    if (bytes + 64 > c->cap_bytes) {
+        const uint64_t nb = bytes + bytes / 8 + 4096;
+        c->cap_bytes = 0;
+        int rc;
+        if ((rc = grow(c, c->d_in, nb))) return rc;
+        if ((rc = grow(c, c->d_out, nb))) return rc;
+        c->cap_bytes = nb;
+    }
+    if (recs + 1 > c->cap_rec) {
+        const uint64_t nr = recs + recs / 8 + 1024;
+        c->cap_rec = 0;
+        int rc;
+        if ((rc = grow(c, c->d_off, nr))) return rc;
+        if ((rc = grow(c, c->d_idx, nr))) return rc;
+        if ((rc = grow(c, c->d_strand, nr))) return rc;
+        if ((rc = grow(c, c->d_hash, nr))) return rc;
+        c->cap_rec = nr;
+    }
+    return CIRCKIT_OK;
+}
+
+int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* out,
+               uint32_t* idx, uint8_t* strand, uint64_t* hash, uint32_t flags)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    if (n && (!offsets || offsets[0] != 0)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "offsets[0] must be 0");
+    if (n == 0) return CIRCKIT_OK;
+    const uint64_t total = offsets[n];
+    if (total && !bytes) return fail(c, CIRCKIT_ERR_INVALID_ARG, "bytes is NULL");
+    CK_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, total, n);
+    if (rc) return rc;
+    if (total) CK_HIP(c, hipMemcpyAsync(c->d_in, bytes, total, hipMemcpyHostToDevice, c->stream));
+    CK_HIP(c, hipMemcpyAsync(c->d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    const bool need_bytes = out || hash;
+    rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
+                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags);
+    if (rc) return rc;
+    if (out && total) CK_HIP(c, hipMemcpyAsync(out, c->d_out, total, hipMemcpyDeviceToHost, c->stream));
+    if (idx) CK_HIP(c, hipMemcpyAsync(idx, c->d_idx, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (strand) CK_HIP(c, hipMemcpyAsync(strand, c->d_strand, n, hipMemcpyDeviceToHost, c->stream));
+    if (hash) CK_HIP(c, hipMemcpyAsync(hash, c->d_hash, n * 8, hipMemcpyDeviceToHost, c->stream));
+    uint32_t unprocessed = 0;
+    CK_HIP(c, hipMemcpyAsync(&unprocessed, c->d_counters + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    if (unprocessed)
+        return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) exceed the largest LDS tier and were not processed", unprocessed);
+    return CIRCKIT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* circkit_version(void) { return "circkit-mi355x 0.1.0 (gfx950)"; }
+
+int circkit_ctx_create(int device, circkit_ctx** out)
+{
+    if (!out) return CIRCKIT_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return CIRCKIT_ERR_NO_DEVICE;
+    circkit_ctx* c = new circkit_ctx();
+    c->device = device;
+    *out = c;   // handed out even on failure below so the caller can read last_error, then destroy
+    CK_HIP(c, hipSetDevice(device));
+    CK_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CK_HIP(c, hipEventCreate(&c->ev0));
+    CK_HIP(c, hipEventCreate(&c->ev1));
+    CK_HIP(c, hipMalloc(&c->d_comp, 256));
+    CK_HIP(c, hipMalloc(&c->d_counters, 8 * sizeof(uint32_t)));
+    CK_HIP(c, hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
+    uint8_t comp[256];
+    for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
+    // bio 1.3.1 alphabets::dna complement table (call site lib/src/canonicalize.rs:56)
+    const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
+    for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = (uint8_t)y[i]; comp[(uint8_t)x[i] + 32] = (uint8_t)(y[i] + 32); }
+    CK_HIP(c, hipMemcpy(c->d_comp, comp, 256, hipMemcpyHostToDevice));
+    CK_HIP(c, hipFuncSetAttribute((const void*)canon_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(TIER_C_DW * 4)));
+    return CIRCKIT_OK;
+}
+
+int circkit_ctx_destroy(circkit_ctx* c)
+{
+    if (!c) return CIRCKIT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    void* ptrs[] = { c->d_comp, c->d_counters, c->d_list_a, c->d_list_b, c->d_in, c->d_out, c->d_strand, c->d_off,
+                     c->d_idx, c->d_hash, c->d_keys, c->d_vals };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return CIRCKIT_OK;
+}
+
+const char* circkit_last_error(const circkit_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int circkit_ctx_set_stream(circkit_ctx* c, void* s)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return CIRCKIT_OK;
+}
+
+int circkit_ctx_synchronize(circkit_ctx* c)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    return CIRCKIT_OK;
+}
+
+int circkit_ctx_last_kernel_ms(circkit_ctx* c, float* ms)
+{
+    if (!c || !ms) return CIRCKIT_ERR_INVALID_ARG;
+    if (!c->timed) return fail(c, CIRCKIT_ERR_INVALID_ARG, "no timed batch yet");
+    CK_HIP(c, hipEventSynchronize(c->ev1));
+    CK_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return CIRCKIT_OK;
+}
+
+int circkit_ctx_batch_status(circkit_ctx* c, uint32_t* n_unprocessed)
+{
+    if (!c || !n_unprocessed) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    CK_HIP(c, hipMemcpyAsync(n_unprocessed, c->d_counters + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    return *n_unprocessed ? CIRCKIT_ERR_TOO_LONG : CIRCKIT_OK;
+}
+
+int circkit_canonicalize_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                                      uint64_t n, uint8_t* d_out, uint32_t* d_idx, uint8_t* d_strand,
+                                      uint64_t* d_hash)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    if (n && !d_offsets) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_offsets is NULL");
+    return launch_canon(c, d_bytes, d_offsets, n, d_out, d_idx, d_strand, d_hash, 0);
+}
+
+int circkit_lmsr_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                              uint8_t* d_out, uint32_t* d_idx)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    if (n && !d_offsets) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_offsets is NULL");
+    return launch_canon(c, d_bytes, d_offsets, n, d_out, d_idx, nullptr, nullptr, ck::CK_FLAG_FWD_ONLY);
+}
+
+int circkit_canonicalize_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
+                               uint8_t* out, uint32_t* idx, uint8_t* strand, uint64_t* hash)
+{
+    return host_batch(c, bytes, offsets, n, out, idx, strand, hash, 0);
+}
+
+static int check_ascii(circkit_ctx* c, const uint8_t* s, size_t n)
+{
+    if (n && !s) return fail(c, CIRCKIT_ERR_INVALID_ARG, "s is NULL");
+    if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_TOO_LONG, "record too long");
+    for (size_t i = 0; i < n; ++i)
+        if (s[i] & 0x80) return fail(c, CIRCKIT_ERR_NOT_ASCII, "non-ASCII byte at %zu (the reference panics on non-UTF-8 / indexes by char)", i);
+    return CIRCKIT_OK;
+}
+
+int circkit_lmsr_index(circkit_ctx* c, const uint8_t* s, size_t n, size_t* out_index)
+{
+    if (!c || !out_index) return CIRCKIT_ERR_INVALID_ARG;
+    int rc = check_ascii(c, s, n);
+    if (rc) return rc;
+    *out_index = 0;
+    if (n == 0) return CIRCKIT_OK;                      // lib/src/canonicalize.rs:8-11: res stays 0
+    uint64_t off[2] = { 0, (uint64_t)n };
+    uint32_t idx = 0;
+    rc = host_batch(c, s, off, 1, nullptr, &idx, nullptr, nullptr, ck::CK_FLAG_FWD_ONLY);
+    *out_index = idx;
+    return rc;
+}
+
+int circkit_lmsr(circkit_ctx* c, const uint8_t* s, size_t n, uint8_t* out)
+{
+    if (!c || (n && !out)) return CIRCKIT_ERR_INVALID_ARG;
+    int rc = check_ascii(c, s, n);
+    if (rc || n == 0) return rc;
+    uint64_t off[2] = { 0, (uint64_t)n };
+    return host_batch(c, s, off, 1, out, nullptr, nullptr, nullptr, ck::CK_FLAG_FWD_ONLY);
+}
+
+int circkit_canonicalize(circkit_ctx* c, const uint8_t* s, size_t n, uint8_t* out)
+{
+    if (!c || (n && !out)) return CIRCKIT_ERR_INVALID_ARG;
+    int rc = check_ascii(c, s, n);
+    if (rc || n == 0) return rc;
+    uint64_t off[2] = { 0, (uint64_t)n };
+    return host_batch(c, s, off, 1, out, nullptr, nullptr, nullptr, 0);
+}
+
+int circkit_xxh3_64(circkit_ctx* c, const uint8_t* s, size_t n, uint64_t* out_hash)
+{
+    if (!c || !out_hash || (n && !s)) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, n, 1);
+    if (rc) return rc;
+    uint64_t off[2] = { 0, (uint64_t)n };
+    if (n) CK_HIP(c, hipMemcpyAsync(c->d_in, s, n, hipMemcpyHostToDevice, c->stream));
+    CK_HIP(c, hipMemcpyAsync(c->d_off, off, 16, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, c->d_in, c->d_off, (uint64_t)1, c->d_hash);
+    CK_HIP(c, hipMemcpyAsync(out_hash, c->d_hash, 8, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    return CIRCKIT_OK;
+}
+
+int circkit_xxh3_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                              uint64_t* d_hash)
+{
+    if (!c || (n && (!d_offsets || !d_hash))) return CIRCKIT_ERR_INVALID_ARG;
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    const uint64_t blocks = (n + 3) / 4;
+    const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
+    hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_bytes, d_offsets, n, d_hash);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    uint64_t cap = 1024;
+    while (cap < 2 * expected_keys) cap <<= 1;
+    if (cap - 1 != c->uniq_mask || !c->d_keys) {
+        c->uniq_mask = 0;
+        int rc;
+        if ((rc = grow(c, c->d_keys, cap + 1))) return rc;
+        if ((rc = grow(c, c->d_vals, cap + 1))) return rc;
+        c->uniq_mask = cap - 1;
+    }
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_keys, cap + 1, (unsigned long long)UNIQ_EMPTY);
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_vals, cap + 1, (unsigned long long)UNIQ_EMPTY);
+    CK_HIP(c, hipMemsetAsync(c->d_counters + 3, 0, 4, c->stream));
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_insert_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t n, uint64_t base_index)
+{
+    if (!c || (n && !d_hash)) return CIRCKIT_ERR_INVALID_ARG;
+    if (!c->d_keys) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, base_index, c->d_keys,
+                       c->d_vals, c->uniq_mask, c->d_counters + 3);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_lookup_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen)
+{
+    if (!c || (n && (!d_hash || !d_first_seen))) return CIRCKIT_ERR_INVALID_ARG;
+    if (!c->d_keys) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, c->d_keys, c->d_vals,
+                       c->uniq_mask, d_first_seen);
+    CK_HIP(c, hipGetLastError());
+    uint32_t overflow = 0;
+    CK_HIP(c, hipMemcpyAsync(&overflow, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    if (overflow) return fail(c, CIRCKIT_ERR_OOM, "uniq table overflow: more distinct keys than circkit_uniq_reset sized it for");
+    return CIRCKIT_OK;
+}
+
+int circkit_synth_fill_device(circkit_ctx* c, uint64_t seed, uint64_t first_base, uint64_t n_bases, uint8_t* d_bytes)
+{
+    if (!c || (n_bases && !d_bytes)) return CIRCKIT_ERR_INVALID_ARG;
+    if (n_bases == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, seed, first_base, n_bases, d_bytes);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+int circkit_fixed_offsets_device(circkit_ctx* c, uint64_t base, uint64_t len, uint64_t n, uint64_t* d_offsets)
+{
+    if (!c || !d_offsets) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(fixed_offsets_kernel, dim3(N_CU * 4), dim3(256), 0, c->stream, base, len, n, d_offsets);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+// needletail 0.5.1 sequence::normalize(seq, false) -- host logic of the CSR packer.
+size_t circkit_normalize(const uint8_t* s, size_t n, uint8_t* out, int* changed)
+{
+    static uint8_t lut[256];
+    static bool ready = false;
+    if (!ready) {
+        for (int v = 0; v < 256; ++v) lut[v] = 'N';
+        const char* keep = "ACGTN-";
+        for (int i = 0; keep[i]; ++i) lut[(uint8_t)keep[i]] = (uint8_t)keep[i];
+        lut['a'] = 'A'; lut['c'] = 'C'; lut['g'] = 'G'; lut['t'] = 'T'; lut['u'] = 'T'; lut['U'] = 'T';
+        lut['.'] = '-'; lut['~'] = '-';
+        lut[' '] = 0; lut['\t'] = 0; lut['\r'] = 0; lut['\n'] = 0;
+        ready = true;
+    }
+    size_t m = 0; int ch = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t c = s[i], o = lut[c];
+        ch |= (o != c);
+        out[m] = o;
+        m += (o != 0);
+    }
+    if (changed) *changed = ch;
+    return m;
+}
+
+}  // extern "C"

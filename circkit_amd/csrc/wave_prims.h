@@ -3,7 +3,7 @@
 // Device build (hipcc, gfx950): thin wrappers over CDNA4 intrinsics (64-lane ballot, ds_bpermute,
 // v_perm_b32, v_alignbit_b32, DPP-based reductions).
 // CK_EMU build (g++, tests only): the same kernel source runs as 64 cooperatively scheduled fibers
-// per wave (tests/emu/), so kernel logic can be checked against the oracle on a machine without a
+// per wave (tests/emu/), so kernel logic can be checked against the CPU checker on a machine without a
 // GPU.  The emulator is test infrastructure: it is never linked into libcirckit_hip.so.
 //
 // Discipline the kernels keep (and the emulator asserts): every collective (ballot / shfl / readlane /

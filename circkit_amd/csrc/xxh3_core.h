@@ -1,0 +1,170 @@
+// xxh3_core.h -- XXH3-64 (seed 0, default secret) of one record by one wavefront.
+//
+// Replaces `xxhash_rust::xxh3::xxh3_64(canonicalized)` (reference src/uniq.rs:45; xxhash-rust 0.8.6
+// implements the published XXH3 algorithm).  Written from the XXH3 specification.
+//
+// Long inputs (> 240 B): a 1024-byte block is 16 stripes x 4 accumulator pairs = 64 independent
+// (stripe, pair) cells of 16 bytes -- exactly one cell per lane.  Between scrambles the accumulators
+// are plain sums modulo 2^64, so the cells are combined with a 4-step xor-butterfly over the stripe
+// bits of the lane id; lane t ends up holding accumulators (2j, 2j+1), j = t & 3.
+#pragma once
+#include "wave_prims.h"
+
+namespace ck {
+
+#ifndef CK_EMU
+#define CK_CONST __device__ __constant__
+#else
+#define CK_CONST static const
+#endif
+
+CK_CONST uint8_t XXH3_SECRET[192] = {
+    0xb8, 0xfe, 0x6c, 0x39, 0x23, 0xa4, 0x4b, 0xbe, 0x7c, 0x01, 0x81, 0x2c, 0xf7, 0x21, 0xad, 0x1c,
+    0xde, 0xd4, 0x6d, 0xe9, 0x83, 0x90, 0x97, 0xdb, 0x72, 0x40, 0xa4, 0xa4, 0xb7, 0xb3, 0x67, 0x1f,
+    0xcb, 0x79, 0xe6, 0x4e, 0xcc, 0xc0, 0xe5, 0x78, 0x82, 0x5a, 0xd0, 0x7d, 0xcc, 0xff, 0x72, 0x21,
+    0xb8, 0x08, 0x46, 0x74, 0xf7, 0x43, 0x24, 0x8e, 0xe0, 0x35, 0x90, 0xe6, 0x81, 0x3a, 0x26, 0x4c,
+    0x3c, 0x28, 0x52, 0xbb, 0x91, 0xc3, 0x00, 0xcb, 0x88, 0xd0, 0x65, 0x8b, 0x1b, 0x53, 0x2e, 0xa3,
+    0x71, 0x64, 0x48, 0x97, 0xa2, 0x0d, 0xf9, 0x4e, 0x38, 0x19, 0xef, 0x46, 0xa9, 0xde, 0xac, 0xd8,
+    0xa8, 0xfa, 0x76, 0x3f, 0xe3, 0x9c, 0x34, 0x3f, 0xf9, 0xdc, 0xbb, 0xc7, 0xc7, 0x0b, 0x4f, 0x1d,
+    0x8a, 0x51, 0xe0, 0x4b, 0xcd, 0xb4, 0x59, 0x31, 0xc8, 0x9f, 0x7e, 0xc9, 0xd9, 0x78, 0x73, 0x64,
+    0xea, 0xc5, 0xac, 0x83, 0x34, 0xd3, 0xeb, 0xc3, 0xc5, 0x81, 0xa0, 0xff, 0xfa, 0x13, 0x63, 0xeb,
+    0x17, 0x0d, 0xdd, 0x51, 0xb7, 0xf0, 0xda, 0x49, 0xd3, 0x16, 0x55, 0x26, 0x29, 0xd4, 0x68, 0x9e,
+    0x2b, 0x16, 0xbe, 0x58, 0x7d, 0x47, 0xa1, 0xfc, 0x8f, 0xf8, 0xb8, 0xd1, 0x7a, 0xd0, 0x31, 0xce,
+    0x45, 0xcb, 0x3a, 0x8f, 0x95, 0x16, 0x04, 0x28, 0xaf, 0xd7, 0xfb, 0xca, 0xbb, 0x4b, 0x40, 0x7e,
+};
+
+constexpr uint64_t XP32_1 = 0x9E3779B1ull, XP32_2 = 0x85EBCA77ull, XP32_3 = 0xC2B2AE3Dull;
+constexpr uint64_t XP64_1 = 0x9E3779B185EBCA87ull, XP64_2 = 0xC2B2AE3D27D4EB4Full, XP64_3 = 0x165667B19E3779F9ull,
+                   XP64_4 = 0x85EBCA77C2B2AE63ull, XP64_5 = 0x27D4EB2F165667C5ull;
+constexpr uint64_t XPMX1 = 0x165667919E3779F9ull, XPMX2 = 0x9FB21C651E98DF25ull;
+
+CK_DEV uint64_t xsec64(uint32_t o)
+{
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) v = (v << 8) | XXH3_SECRET[o + i];
+    return v;
+}
+CK_DEV uint32_t xsec32(uint32_t o) { return (uint32_t)xsec64(o); }
+CK_DEV uint64_t xrd64(const uint8_t* p) { return (uint64_t)load4(p) | ((uint64_t)load4(p + 4) << 32); }
+CK_DEV uint64_t xrotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+CK_DEV uint64_t xswap64(uint64_t x)
+{
+    x = ((x & 0x00FF00FF00FF00FFull) << 8) | ((x >> 8) & 0x00FF00FF00FF00FFull);
+    x = ((x & 0x0000FFFF0000FFFFull) << 16) | ((x >> 16) & 0x0000FFFF0000FFFFull);
+    return (x << 32) | (x >> 32);
+}
+CK_DEV uint64_t xmulhi(uint64_t a, uint64_t b)
+{
+#ifndef CK_EMU
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((__uint128_t)a * b) >> 64);
+#endif
+}
+CK_DEV uint64_t xfold(uint64_t a, uint64_t b) { return (a * b) ^ xmulhi(a, b); }
+CK_DEV uint64_t xaval3(uint64_t h) { h ^= h >> 37; h *= XPMX1; return h ^ (h >> 32); }
+CK_DEV uint64_t xaval64(uint64_t h)
+{
+    h ^= h >> 33; h *= XP64_2; h ^= h >> 29; h *= XP64_3; return h ^ (h >> 32);
+}
+CK_DEV uint64_t xmix16(const uint8_t* in, uint32_t so)
+{
+    return xfold(xrd64(in) ^ xsec64(so), xrd64(in + 8) ^ xsec64(so + 8));
+}
+
+// Lengths <= 240: every lane computes the same scalar recipe (addresses are wave-uniform).
+CK_DEV uint64_t xxh3_short(const uint8_t* in, uint32_t len)
+{
+    if (len == 0) return xaval64(xsec64(56) ^ xsec64(64));
+    if (len <= 3) {
+        const uint32_t c1 = in[0], c2 = in[len >> 1], c3 = in[len - 1];
+        const uint32_t comb = (c1 << 16) | (c2 << 24) | c3 | (len << 8);
+        return xaval64((uint64_t)comb ^ (uint64_t)(xsec32(0) ^ xsec32(4)));
+    }
+    if (len <= 8) {
+        const uint64_t i1 = load4(in), i2 = load4(in + len - 4);
+        uint64_t h = (i2 + (i1 << 32)) ^ (xsec64(8) ^ xsec64(16));
+        h ^= xrotl(h, 49) ^ xrotl(h, 24);
+        h *= XPMX2; h ^= (h >> 35) + len; h *= XPMX2;
+        return h ^ (h >> 28);
+    }
+    if (len <= 16) {
+        const uint64_t lo = xrd64(in) ^ (xsec64(24) ^ xsec64(32)), hi = xrd64(in + len - 8) ^ (xsec64(40) ^ xsec64(48));
+        return xaval3((uint64_t)len + xswap64(lo) + hi + xfold(lo, hi));
+    }
+    if (len <= 128) {
+        uint64_t acc = (uint64_t)len * XP64_1;
+        if (len > 32) {
+            if (len > 64) {
+                if (len > 96) { acc += xmix16(in + 48, 96); acc += xmix16(in + len - 64, 112); }
+                acc += xmix16(in + 32, 64); acc += xmix16(in + len - 48, 80);
+            }
+            acc += xmix16(in + 16, 32); acc += xmix16(in + len - 32, 48);
+        }
+        acc += xmix16(in, 0); acc += xmix16(in + len - 16, 16);
+        return xaval3(acc);
+    }
+    uint64_t acc = (uint64_t)len * XP64_1;
+    const uint32_t rounds = len / 16;
+    for (uint32_t i = 0; i < 8; ++i) acc += xmix16(in + 16 * i, 16 * i);
+    acc = xaval3(acc);
+    for (uint32_t i = 8; i < rounds; ++i) acc += xmix16(in + 16 * i, 16 * (i - 8) + 3);
+    acc += xmix16(in + len - 16, 136 - 17);
+    return xaval3(acc);
+}
+
+// One 16-byte cell: contributions to accumulators (2j, 2j+1) from data words d0,d1 with secret offset so.
+CK_DEV void xcell(uint64_t d0, uint64_t d1, uint32_t so, uint64_t& a0, uint64_t& a1)
+{
+    const uint64_t k0 = d0 ^ xsec64(so), k1 = d1 ^ xsec64(so + 8);
+    a0 += d1 + (uint64_t)(uint32_t)k0 * (k0 >> 32);
+    a1 += d0 + (uint64_t)(uint32_t)k1 * (k1 >> 32);
+}
+
+CK_DEV uint64_t xsum_stripes(uint64_t v)   // sum over the 16 lanes that share (lane & 3)
+{
+#pragma unroll
+    for (uint32_t m = 4; m <= 32; m <<= 1) {
+        const uint32_t lo = shfl((uint32_t)v, lane_id() ^ m), hi = shfl((uint32_t)(v >> 32), lane_id() ^ m);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len)
+{
+    if (len <= 240) return xxh3_short(in, len);
+    const uint32_t lane = lane_id(), j = lane & 3, s = lane >> 2;
+    // accumulator init: {P32_3, P64_1, P64_2, P64_3, P64_4, P32_2, P64_5, P32_1}
+    uint64_t a0 = j == 0 ? XP32_3 : j == 1 ? XP64_2 : j == 2 ? XP64_4 : XP64_5;
+    uint64_t a1 = j == 0 ? XP64_1 : j == 1 ? XP64_3 : j == 2 ? XP32_2 : XP32_1;
+    const uint32_t nb = (len - 1) / 1024;
+    for (uint32_t b = 0; b <= nb; ++b) {
+        const uint32_t stripes = b < nb ? 16u : ((len - 1) - 1024 * nb) / 64;
+        uint64_t c0 = 0, c1 = 0;
+        if (s < stripes) {
+            const uint8_t* p = in + 1024 * b + 16 * lane;
+            xcell(xrd64(p), xrd64(p + 8), 8 * s + 16 * j, c0, c1);
+        }
+        a0 += xsum_stripes(c0);
+        a1 += xsum_stripes(c1);
+        if (b < nb) {   // scramble with the last 64 secret bytes
+            a0 = (a0 ^ (a0 >> 47) ^ xsec64(128 + 16 * j)) * XP32_1;
+            a1 = (a1 ^ (a1 >> 47) ^ xsec64(128 + 16 * j + 8)) * XP32_1;
+        }
+    }
+    {   // last stripe: the final 64 bytes, secret offset 192 - 64 - 7
+        const uint8_t* p = in + len - 64 + 16 * j;
+        xcell(xrd64(p), xrd64(p + 8), 121 + 16 * j, a0, a1);
+    }
+    uint64_t t = xfold(a0 ^ xsec64(11 + 16 * j), a1 ^ xsec64(11 + 16 * j + 8));
+#pragma unroll
+    for (uint32_t m = 1; m <= 2; m <<= 1) {
+        const uint32_t lo = shfl((uint32_t)t, lane ^ m), hi = shfl((uint32_t)(t >> 32), lane ^ m);
+        t += ((uint64_t)hi << 32) | lo;
+    }
+    return xaval3((uint64_t)len * XP64_1 + t);
+}
+
+}  // namespace ck

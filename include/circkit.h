@@ -1,0 +1,138 @@
+/*
+ * circkit.h -- C ABI of the MI355X (gfx950) drop-in for circkit's `canonicalize` / `uniq` hot path.
+ *
+ * The reference (Benjamin-Lee/circkit, Rust) has no FFI: the seam this library sits behind is the
+ * lib-crate API plus the two closures the CLI hands to seq_io::parallel_fasta.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference checkout); INTEGRATION.md
+ * shows the `extern "C"` block a maintainer would add on the Rust side.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; caller allocates and owns every buffer; the library keeps no
+ *    pointer after a call returns (device entry points: after the stream work completes).
+ *  - return value 0 = CIRCKIT_OK, negative = error; no exceptions or panics cross the ABI;
+ *    circkit_last_error(ctx) gives the message of the last failing call on that ctx.
+ *  - one ctx per GPU, used by one host thread at a time; ctxs are independent (multi-GPU = one ctx,
+ *    one process or thread, per device).
+ *  - there is NO CPU fallback: every compute entry point runs the HIP kernels and fails with
+ *    CIRCKIT_ERR_NO_DEVICE / CIRCKIT_ERR_HIP when it cannot.
+ *  - CSR batches: bytes[offsets[i] .. offsets[i+1]) is record i; offsets has n_records + 1 entries,
+ *    offsets[0] may be non-zero; records are what the reference's worker closure hands to
+ *    circkit::canonicalize, i.e. already normalized (src/canonicalize.rs:24-29).  A record may be any
+ *    byte string; records of pure ACGT take the 2-bit path, {-,A,C,G,N,T} the 4-bit path, everything
+ *    else the byte-wide path (unsigned byte order, as the reference's slice comparison).
+ */
+#ifndef CIRCKIT_H
+#define CIRCKIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIRCKIT_OK 0
+#define CIRCKIT_ERR_INVALID_ARG (-1)
+#define CIRCKIT_ERR_NO_DEVICE (-2)   /* no HIP device / device index out of range */
+#define CIRCKIT_ERR_HIP (-3)         /* a HIP runtime call or kernel failed */
+#define CIRCKIT_ERR_TOO_LONG (-4)    /* a record exceeds what one workgroup's LDS can hold */
+#define CIRCKIT_ERR_OOM (-5)
+#define CIRCKIT_ERR_NOT_ASCII (-6)   /* single-record API only: mirrors the reference's from_utf8().unwrap() panic */
+
+typedef struct circkit_ctx circkit_ctx;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+/* Replaces: nothing in the reference (it is a single CPU process); one ctx ~ one worker pool
+ * (`--threads`, src/commands.rs:120-123) bound to one GPU. */
+int circkit_ctx_create(int device, circkit_ctx** out);
+int circkit_ctx_destroy(circkit_ctx* ctx);
+const char* circkit_last_error(const circkit_ctx* ctx);
+/* Launch all subsequent work of this ctx on `hip_stream` (a hipStream_t; NULL = the ctx's own stream). */
+int circkit_ctx_set_stream(circkit_ctx* ctx, void* hip_stream);
+/* Block until all work queued by this ctx has finished. */
+int circkit_ctx_synchronize(circkit_ctx* ctx);
+/* Milliseconds the canonicalize kernels of the most recent *_batch_device call took on the GPU
+ * (hipEvent pair recorded on the launch stream around the kernels; synchronizes on the stop event). */
+int circkit_ctx_last_kernel_ms(circkit_ctx* ctx, float* ms);
+
+/* ---- batch, device resident (the hot path) ---------------------------------------------------- */
+/* Replaces, for a whole batch of records: the worker-closure body `circkit::canonicalize(&normalized)`
+ * (src/canonicalize.rs:29, src/uniq.rs:40) = lib/src/canonicalize.rs:54-63 (lmsr x2 + revcomp + select),
+ * and, when d_out_xxh3 is given, `xxh3_64(canonicalized)` (src/uniq.rs:45).
+ * All pointers are DEVICE pointers; the call only enqueues work on the ctx stream.
+ *   d_bytes      payload; must be readable for total_bytes (= offsets[n_records]) bytes
+ *   d_offsets    uint64[n_records + 1]
+ *   d_out_bytes  nullable; canonical sequences, same offsets as the input
+ *   d_out_index  nullable; uint32[n_records]: lmsr_index(s) when the forward strand wins, else
+ *                lmsr_index(revcomp(lmsr(s))) -- the two indices the reference computes (:43, :56)
+ *   d_out_strand nullable; uint8[n_records]: 0 = lmsr(s) returned, 1 = lmsr(revcomp) returned (:58-62)
+ *   d_out_xxh3   nullable; uint64[n_records]: XXH3-64 (seed 0) of the canonical sequence
+ * n_records must be < 2^32 and every record shorter than 2^31 bytes. */
+int circkit_canonicalize_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                                      uint64_t n_records, uint8_t* d_out_bytes, uint32_t* d_out_index,
+                                      uint8_t* d_out_strand, uint64_t* d_out_xxh3);
+
+/* lmsr() for a whole batch: forward strand only (lib/src/canonicalize.rs:41-47); d_out_index[i] =
+ * lmsr_index(record i) (lib/src/canonicalize.rs:5). */
+int circkit_lmsr_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                              uint64_t n_records, uint8_t* d_out_bytes, uint32_t* d_out_index);
+/* xxh3_64 (call site src/uniq.rs:45) of every record of a device-resident CSR batch. */
+int circkit_xxh3_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                              uint64_t n_records, uint64_t* d_out_xxh3);
+
+/* Number of records of the most recent batch that no LDS tier could hold (they were left untouched);
+ * non-zero makes the batch call's status CIRCKIT_ERR_TOO_LONG when queried here.  Synchronizes. */
+int circkit_ctx_batch_status(circkit_ctx* ctx, uint32_t* n_unprocessed);
+
+/* ---- batch, host buffers ---------------------------------------------------------------------- */
+/* Same contract with HOST pointers: copies the batch to the device (pinned staging, chunked, copy
+ * overlapped with compute), runs circkit_canonicalize_batch_device, copies the requested outputs back
+ * and returns when they are complete.  offsets[0] must be 0. */
+int circkit_canonicalize_batch(circkit_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets,
+                               uint64_t n_records, uint8_t* out_bytes, uint32_t* out_index,
+                               uint8_t* out_strand, uint64_t* out_xxh3);
+
+/* ---- single record: 1:1 mirror of the lib crate (lib/src/lib.rs:1,3) ------------------------------ */
+/* pub fn lmsr_index(x: &[u8]) -> usize            lib/src/canonicalize.rs:5  */
+int circkit_lmsr_index(circkit_ctx* ctx, const uint8_t* s, size_t n, size_t* out_index);
+/* pub fn lmsr(s: &[u8]) -> Vec<u8>                lib/src/canonicalize.rs:41  (out has n bytes) */
+int circkit_lmsr(circkit_ctx* ctx, const uint8_t* s, size_t n, uint8_t* out);
+/* pub fn canonicalize(s: &[u8]) -> Vec<u8>        lib/src/canonicalize.rs:54  (out has n bytes) */
+int circkit_canonicalize(circkit_ctx* ctx, const uint8_t* s, size_t n, uint8_t* out);
+/* xxhash_rust::xxh3::xxh3_64(bytes)               call site src/uniq.rs:45 */
+int circkit_xxh3_64(circkit_ctx* ctx, const uint8_t* s, size_t n, uint64_t* out_hash);
+
+/* ---- uniq: first-seen resolution on the device ------------------------------------------------ */
+/* Replaces the `seen: HashMap<u64, String, NoHash>` logic of src/uniq.rs:27,47-48,66: for every record
+ * i, d_first_seen[i] = the smallest global index whose hash equals d_hash[i] (hash-only equality, as in
+ * the reference); record i is kept iff d_first_seen[i] == base_index + i.
+ * `base_index` is the global index of record 0 of this batch (multi-GPU sharding / streaming batches).
+ * The table persists in the ctx across calls until circkit_uniq_reset, so batches (and hash sets
+ * gathered from other GPUs) can be folded in one after another:
+ *   circkit_uniq_insert_device   folds (hash, global index) pairs into the table
+ *   circkit_uniq_lookup_device   reads the winner for each hash */
+int circkit_uniq_reset(circkit_ctx* ctx, uint64_t expected_keys);
+int circkit_uniq_insert_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t base_index);
+int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen);
+
+/* ---- synthetic input on the device (bench / tests) ------------------------------ */
+/* Fills d_bytes[0..n_bases) with uniform ACGT from the counter-based generator keyed by
+ * (seed, first_base + i) -- the same bytes oracle/ck_oracle_synth_fill produces on the host. */
+int circkit_synth_fill_device(circkit_ctx* ctx, uint64_t seed, uint64_t first_base, uint64_t n_bases,
+                              uint8_t* d_bytes);
+/* d_offsets[i] = base + i * record_len for i in 0..n_records (inclusive). */
+int circkit_fixed_offsets_device(circkit_ctx* ctx, uint64_t base, uint64_t record_len, uint64_t n_records,
+                                 uint64_t* d_offsets);
+
+/* ---- host-side normalisation used by the packer ------------------------------------------------ */
+/* needletail::sequence::normalize(seq, false)      call sites src/canonicalize.rs:24, src/uniq.rs:35
+ * Host logic of the CSR packer (strips line breaks while it computes offsets); returns the new length,
+ * sets *changed to 0 when the reference would have returned None. */
+size_t circkit_normalize(const uint8_t* s, size_t n, uint8_t* out, int* changed);
+
+const char* circkit_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIRCKIT_H */

@@ -90,6 +90,7 @@ void run_wave(void (*body)(void*), void* arg)
 }}  // namespace ck::emu
 
 #include "../../circkit_amd/csrc/canon_core.h"
+#include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
 struct Launch { ck::CanonArgs a; uint32_t* lds; uint32_t wave_id, n_waves; };
@@ -103,7 +104,7 @@ void wave_body(void* p)
 extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                       uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
                                       uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
-                                      uint32_t* n_deferred)
+                                      uint32_t* n_deferred, uint32_t flags)
 {
     uint8_t comp[256];
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
@@ -113,7 +114,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     uint32_t defer_count = 0, status = 0;
     Launch L;
     L.a = ck::CanonArgs{ bytes, offsets, n_records, out_bytes, out_index, out_strand, out_hash,
-                         nullptr, nullptr, deferred.data(), &defer_count, &status, comp, slice_dw };
+                         nullptr, nullptr, deferred.data(), &defer_count, &status, comp, slice_dw, flags };
     L.lds = lds.data();
     L.n_waves = n_waves;
     for (uint32_t w = 0; w < n_waves; ++w) {
@@ -122,4 +123,22 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     }
     if (n_deferred) *n_deferred = defer_count;
     return (int)status;
+}
+
+namespace {
+struct HashLaunch { const uint8_t* p; uint32_t n; uint64_t out[64]; };
+void hash_body(void* q)
+{
+    HashLaunch* H = (HashLaunch*)q;
+    H->out[ck::lane_id()] = ck::xxh3_64_wave(H->p, H->n);
+}
+}
+
+extern "C" uint64_t emu_xxh3_64(const uint8_t* p, uint32_t n)
+{
+    HashLaunch H{ p, n, {0} };
+    ck::emu::run_wave(hash_body, &H);
+    for (int i = 1; i < 64; ++i)
+        if (H.out[i] != H.out[0]) { fprintf(stderr, "emu: xxh3 lanes disagree\n"); abort(); }
+    return H.out[0];
 }

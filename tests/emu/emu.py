@@ -21,12 +21,12 @@ def build():
 _lib = None
 
 
-def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False):
+def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.emu_canonicalize_batch.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4 + \
-            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
@@ -39,6 +39,16 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False)
     ndef = ctypes.c_uint32(0)
     st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data, idx.ctypes.data,
                                      strand.ctypes.data, hs.ctypes.data if want_hash else None,
-                                     slice_dw, n_waves, ctypes.byref(ndef))
+                                     slice_dw, n_waves, ctypes.byref(ndef), flags)
     assert (out[len(data):] == 0x3F).all(), "kernel wrote past the end of the output buffer"
     return out[:len(data)], idx[:n], strand[:n], hs[:n], st, ndef.value
+
+
+def xxh3_64(b):
+    global _lib
+    if _lib is None:
+        canonicalize_batch(np.zeros(0, dtype=np.uint8), np.zeros(1, dtype=np.uint64))
+    _lib.emu_xxh3_64.restype = ctypes.c_uint64
+    _lib.emu_xxh3_64.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+    buf = ctypes.create_string_buffer(bytes(b) + b"\0" * 16, len(b) + 16)
+    return int(_lib.emu_xxh3_64(ctypes.addressof(buf), len(b)))

@@ -1,0 +1,74 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/circkit.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "circkit.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(circkit_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    import circkit_amd
+    return circkit_amd.load_library()
+
+
+def test_header_declares_the_expected_surface():
+    syms = header_symbols()
+    for must in ("circkit_ctx_create", "circkit_canonicalize_batch_device", "circkit_canonicalize_batch",
+                 "circkit_lmsr_index", "circkit_lmsr", "circkit_canonicalize", "circkit_xxh3_64",
+                 "circkit_uniq_insert_device", "circkit_normalize"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from circkit_amd import api
+    syms = header_symbols()
+    for s in syms:
+        assert hasattr(lib, s), "libcirckit_hip.so does not export %s" % s
+        assert s in api.SIGNATURES, "api.py has no ctypes signature for %s" % s
+    assert sorted(api.SIGNATURES) == syms
+
+
+def test_version_and_host_normalize(lib):
+    import circkit_amd
+    assert b"gfx950" in lib.circkit_version()
+    # needletail normalize cases pinned by the reference fixtures + recalled doc examples
+    assert circkit_amd.normalize(b"ACGTU") == (b"ACGTT", True)
+    assert circkit_amd.normalize(b"acgtu") == (b"ACGTT", True)
+    assert circkit_amd.normalize(b"N.N-N~N N") == (b"N-N-N-NN", True)
+    assert circkit_amd.normalize(b"BDHVRYSWKM") == (b"NNNNNNNNNN", True)
+    assert circkit_amd.normalize(b"ACGTN-") == (b"ACGTN-", False)
+    assert circkit_amd.normalize(b"TT\nATG\r\n") == (b"TTATG", True)
+    from oracle import oracle as O
+    import random
+    rng = random.Random(9)
+    for _ in range(300):
+        s = bytes(rng.randrange(256) for _ in range(rng.randint(0, 80)))
+        assert circkit_amd.normalize(s) == O.normalize(s)
+
+
+def test_no_device_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import circkit_amd
+    with pytest.raises(circkit_amd.CirckitError) as e:
+        circkit_amd.Context(0)
+    assert e.value.code == -2          # CIRCKIT_ERR_NO_DEVICE: no CPU fallback
+
+
+def test_product_does_not_reference_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "circkit_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                assert "oracle" not in open(os.path.join(dirpath, f), errors="ignore").read().lower(), f

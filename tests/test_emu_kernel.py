@@ -62,3 +62,21 @@ def test_wave_count_independent():
     a = emu.canonicalize_batch(data, offs, n_waves=1)
     b = emu.canonicalize_batch(data, offs, n_waves=7)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_xxh3_wave_matches_golden_vectors():
+    import json, os
+    vecs = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "xxh3_vectors.json")))["vectors"]
+    for v in vecs:
+        b = v["in"].encode() if "in" in v else v["in_latin1"].encode("latin-1")
+        assert "%016x" % emu.xxh3_64(b) == v["xxh3_64"], len(b)
+
+
+def test_lmsr_forward_only_flag():
+    seqs = seqsets.random_mixed(33, 60, 1, 400) + [b"banana", b"TAA", b"AAA"]
+    data, offs = seqsets.pack(seqs)
+    out, idx, strand, _, status, ndef = emu.canonicalize_batch(data, offs, flags=1)
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == O.lmsr(s)
+        assert int(idx[i]) == O.lmsr_index(s) and int(strand[i]) == 0

@@ -1,0 +1,216 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the
+CPU oracle on the same inputs, against the committed golden fixtures, and -- at BASELINE.json's full
+sizes -- through size-independent properties (idempotence, rotation / strand invariance, hash agreement)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import circkit_amd
+    c = circkit_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    oracle.lib()
+    return oracle
+
+
+def _check(ctx, O, seqs, hashes=True):
+    from tests import seqsets
+    data, offs = seqsets.pack(seqs)
+    got = ctx.canonicalize_batch(data, offs, want_bytes=True, want_index=True, want_strand=True, want_xxh3=hashes)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    if not np.array_equal(got["bytes"], exp):
+        for i, s in enumerate(seqs):
+            a, b = int(offs[i]), int(offs[i + 1])
+            assert got["bytes"][a:b].tobytes() == exp[a:b].tobytes(), (i, len(s), s[:80])
+    if hashes:
+        assert np.array_equal(got["xxh3"], exp_h)
+    for i, s in enumerate(seqs):
+        _, st, idx = seqsets.expected(O, s)
+        assert int(got["strand"][i]) == st, (i, s[:80])
+        if s:
+            assert int(got["index"][i]) == idx, (i, s[:80])
+
+
+def test_reference_known_answers_single_record_api(ctx):
+    ka = json.load(open(os.path.join(GOLDEN, "ref_known_answers.json")))
+    for v in ka["lmsr_index"]:
+        assert ctx.lmsr_index(v["in"].encode()) == v["out"]
+    for v in ka["lmsr"]:
+        assert ctx.lmsr(v["in"].encode()) == v["out"].encode()
+    for v in ka["canonicalize"]:
+        assert ctx.canonicalize(v["in"].encode()) == v["out"].encode()
+    for v in ka["lmsr_idempotent"]:
+        a = ctx.lmsr(v["in"].encode())
+        assert ctx.lmsr(a) == a
+    for v in ka["canonicalize_equal_pairs"]:
+        assert ctx.lmsr(v["a"].encode()) == ctx.lmsr(v["b"].encode())
+        assert ctx.canonicalize(v["a"].encode()) == ctx.canonicalize(v["b"].encode())
+    assert ctx.lmsr_index(b"") == 0 and ctx.lmsr(b"") == b"" and ctx.canonicalize(b"") == b""
+
+
+def test_single_record_api_rejects_non_ascii(ctx):
+    import circkit_amd
+    with pytest.raises(circkit_amd.CirckitError) as e:
+        ctx.canonicalize(b"AC\xffGT")
+    assert e.value.code == -6
+
+
+def test_xxh3_golden_vectors(ctx):
+    vecs = json.load(open(os.path.join(GOLDEN, "xxh3_vectors.json")))["vectors"]
+    for v in vecs:
+        b = v["in"].encode() if "in" in v else v["in_latin1"].encode("latin-1")
+        assert "%016x" % ctx.xxh3_64(b) == v["xxh3_64"], len(b)
+
+
+def test_reference_fixture_files(ctx, O):
+    """tests/canon_uniq.rs:33-89: canonicalize / uniq --canonicalize on the reference's in.fasta files."""
+    import circkit_amd
+    for d in ("simple", "multiple_sequences", "multiple_sequences_split_lines", "rna_input", "repeated",
+              "compressed_input", "compressed_output"):
+        recs = O.read_fasta(open(os.path.join(GOLDEN, "ref_examples", d, "in.fasta"), "rb").read())
+        want = {O.record_id(h): s.replace(b"\n", b"") for h, s in
+                O.read_fasta(open(os.path.join(GOLDEN, "ref_examples", d, "out.fasta"), "rb").read())}
+        got, seen = {}, set()
+        for head, raw in recs:
+            canon = ctx.canonicalize(circkit_amd.normalize(raw)[0])
+            if d != "repeated":
+                got[O.record_id(head)] = canon
+            h = ctx.xxh3_64(canon)
+            if d == "repeated" and h not in seen:
+                got[O.record_id(head)] = canon
+            seen.add(h)
+        assert got == want, d
+
+
+def test_adversarial_set(ctx, O):
+    from tests import seqsets
+    _check(ctx, O, seqsets.adversarial())
+
+
+def test_random_sets_all_alphabets(ctx, O):
+    from tests import seqsets
+    _check(ctx, O, seqsets.random_mixed(41, 4000, 1000, 1000))
+    _check(ctx, O, seqsets.random_mixed(42, 3000, 1, 2500))
+    _check(ctx, O, seqsets.random_mixed(43, 1500, 1, 2500, b"ACGTN"))
+    _check(ctx, O, seqsets.random_mixed(44, 1500, 1, 1500, b"-ACGNT"))
+    _check(ctx, O, seqsets.random_mixed(45, 500, 1, 600, bytes(range(0x21, 0x7F))))
+    _check(ctx, O, seqsets.random_mixed(46, 2000, 1, 400, b"AC"))
+    _check(ctx, O, seqsets.random_mixed(47, 1000, 1, 300, b"A"))
+
+
+def test_realistic_fixture_records(ctx, O):
+    """676 real records (30..1342 nt, some with N) from the reference's nim_cated fixture."""
+    recs = O.read_fasta(open(os.path.join(GOLDEN, "ref_examples", "nim_cated", "realistic_input.fasta"), "rb").read())
+    seqs = [O.normalize(s)[0] for _, s in recs]
+    assert len(seqs) == 676
+    _check(ctx, O, seqs)
+
+
+def test_lds_tiers_long_records(ctx, O):
+    """Records that overflow tier A's 4 KiB slice go to the 40 KiB and 160 KiB tiers (config 4's 20 kb tail)."""
+    from tests import seqsets
+    seqs = seqsets.random_mixed(48, 12, 6000, 20000) + seqsets.random_mixed(49, 4, 3000, 12000, b"ACGTN") + \
+        seqsets.random_mixed(50, 3, 60000, 120000) + [b"ACGT" * 30000, b"A" * 100000] + \
+        seqsets.random_mixed(51, 40, 100, 1000)
+    _check(ctx, O, seqs)
+
+
+def test_too_long_record_is_reported_not_dropped_silently(ctx):
+    import circkit_amd
+    n = 2_000_000
+    data = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(1).integers(0, 4, n)]
+    with pytest.raises(circkit_amd.CirckitError) as e:
+        ctx.canonicalize_batch(data, np.array([0, n], dtype=np.uint64))
+    assert e.value.code == -4
+
+
+def test_zipf_mixed_lengths_config4_shape(ctx, O):
+    """BASELINE config 4 shape at a size the oracle finishes in seconds: 3000 records, L ~ 1/L on [200, 20000]."""
+    rng = np.random.default_rng(45)
+    u = rng.random(3000)
+    lens = np.exp(np.log(200) + u * (np.log(20000) - np.log(200))).astype(np.int64)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    data = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, int(offs[-1]))]
+    got = ctx.canonicalize_batch(data, offs, want_xxh3=True)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    assert np.array_equal(got["bytes"], exp) and np.array_equal(got["xxh3"], exp_h)
+    # variant with ~1 % N
+    data2 = data.copy()
+    data2[rng.random(len(data2)) < 0.01] = ord("N")
+    got = ctx.canonicalize_batch(data2, offs)
+    exp, _ = O.canonicalize_batch(data2, offs, True, False, threads=8)
+    assert np.array_equal(got["bytes"], exp)
+
+
+def test_device_generator_matches_host_generator(ctx, O):
+    import torch
+    n = 1_000_003
+    d = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.synth_fill_device(42, 12345, n, d)
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), O.synth_fill(42, 12345, n))
+    ctx.set_stream(None)
+
+
+def test_full_size_properties_10m_x_1kb(ctx, O):
+    """BASELINE config 2 at full size (10M x 1 kb, device resident): idempotence, strand invariance and
+    rotation invariance of the canonical form, plus byte parity with the oracle on a 20k-record slice."""
+    import torch
+    N, L = 10_000_000, 1000
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    x = torch.empty(N * L + 64, dtype=torch.uint8, device=dev)
+    off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    ctx.synth_fill_device(42, 0, N * L, x)
+    ctx.fixed_offsets_device(0, L, N, off)
+    c1 = torch.empty_like(x)
+    strand = torch.empty(N, dtype=torch.uint8, device=dev)
+    idx = torch.empty(N, dtype=torch.int32, device=dev)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=c1, out_index=idx, out_strand=strand)
+    assert ctx.batch_status() == 0
+    # oracle parity on a slice
+    S = 20000
+    exp, _ = O.canonicalize_batch(x[:S * L].cpu().numpy(), np.arange(S + 1, dtype=np.uint64) * np.uint64(L), True, False, 8)
+    assert np.array_equal(c1[:S * L].cpu().numpy(), exp)
+    # idempotence: canonical input -> identical output, rotation index 0 whenever the forward strand is returned
+    c2 = torch.empty_like(x)
+    s2 = torch.empty_like(strand)
+    i2 = torch.empty_like(idx)
+    ctx.canonicalize_batch_device(c1, off, N, out_bytes=c2, out_index=i2, out_strand=s2)
+    torch.cuda.synchronize()
+    assert torch.equal(c1[:N * L], c2[:N * L])
+    assert int((i2[s2 == 0] != 0).sum().item()) == 0
+    del c2, s2, i2
+    # strand + rotation invariance: reverse-complement every record and rotate it by 137
+    lut = torch.arange(256, dtype=torch.uint8, device=dev)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        lut[a] = b
+    y = torch.empty_like(x)
+    chunk = 1_000_000
+    for s in range(0, N, chunk):
+        v = x[s * L:(s + chunk) * L].view(chunk, L)
+        y[s * L:(s + chunk) * L] = torch.roll(lut[v.flip(1).long()], shifts=137, dims=1).reshape(-1)
+    c3 = torch.empty_like(x)
+    s3 = torch.empty_like(strand)
+    ctx.canonicalize_batch_device(y, off, N, out_bytes=c3, out_strand=s3)
+    torch.cuda.synchronize()
+    assert torch.equal(c1[:N * L], c3[:N * L])
+    # a strict strand decision flips with the input strand (ties = reverse palindromes keep strand 1)
+    assert int(((strand + s3) != 1).sum().item()) <= 5
+    ctx.set_stream(None)
