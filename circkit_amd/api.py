@@ -26,6 +26,7 @@ SIGNATURES = {
     "circkit_ctx_destroy": (_i, [_vp]),
     "circkit_last_error": (ctypes.c_char_p, [_vp]),
     "circkit_ctx_set_stream": (_i, [_vp, _vp]),
+    "circkit_ctx_use_own_stream": (_i, [_vp]),
     "circkit_ctx_synchronize": (_i, [_vp]),
     "circkit_ctx_last_kernel_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "circkit_ctx_batch_status": (_i, [_vp, ctypes.POINTER(_u32)]),
@@ -62,6 +63,13 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # One HIP runtime per process: torch bundles its own libamdhip64 (SONAME libamdhip64.so.7).  Loading
+        # torch first makes our NEEDED libamdhip64.so.7 bind to that copy instead of pulling in /opt/rocm's
+        # as a second runtime (two runtimes in one process cannot both own the GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)      # AttributeError here = header/library mismatch
@@ -112,7 +120,12 @@ class Context:
 
     # -- stream / timing ------------------------------------------------------------------------
     def set_stream(self, stream_handle):
-        self._check(self._lib.circkit_ctx_set_stream(self._h, stream_handle))
+        """Run on this hipStream_t (int handle; 0/None = HIP's default stream), e.g.
+        torch.cuda.current_stream().cuda_stream so the work is ordered with torch's."""
+        self._check(self._lib.circkit_ctx_set_stream(self._h, stream_handle or None))
+
+    def use_own_stream(self):
+        self._check(self._lib.circkit_ctx_use_own_stream(self._h))
 
     def synchronize(self):
         self._check(self._lib.circkit_ctx_synchronize(self._h))

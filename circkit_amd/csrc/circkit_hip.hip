@@ -346,7 +346,14 @@ const char* circkit_last_error(const circkit_ctx* c) { return c ? c->err.c_str()
 int circkit_ctx_set_stream(circkit_ctx* c, void* s)
 {
     if (!c) return CIRCKIT_ERR_INVALID_ARG;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;      // NULL is a real stream: HIP's default (null) stream
+    return CIRCKIT_OK;
+}
+
+int circkit_ctx_use_own_stream(circkit_ctx* c)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    c->stream = c->own_stream;
     return CIRCKIT_OK;
 }
 

@@ -47,8 +47,10 @@ typedef struct circkit_ctx circkit_ctx;
 int circkit_ctx_create(int device, circkit_ctx** out);
 int circkit_ctx_destroy(circkit_ctx* ctx);
 const char* circkit_last_error(const circkit_ctx* ctx);
-/* Launch all subsequent work of this ctx on `hip_stream` (a hipStream_t; NULL = the ctx's own stream). */
+/* Launch all subsequent work of this ctx on `hip_stream` (a hipStream_t; NULL = HIP's default stream).
+ * A fresh ctx launches on a private non-blocking stream; circkit_ctx_use_own_stream returns to it. */
 int circkit_ctx_set_stream(circkit_ctx* ctx, void* hip_stream);
+int circkit_ctx_use_own_stream(circkit_ctx* ctx);
 /* Block until all work queued by this ctx has finished. */
 int circkit_ctx_synchronize(circkit_ctx* ctx);
 /* Milliseconds the canonicalize kernels of the most recent *_batch_device call took on the GPU

@@ -112,6 +112,15 @@ def test_random_sets_all_alphabets(ctx, O):
     _check(ctx, O, seqsets.random_mixed(47, 1000, 1, 300, b"A"))
 
 
+def test_arbitrary_byte_values(ctx, O):
+    """Every byte value (lib API accepts any &[u8]; order = unsigned bytes): byte-wide path, no crash."""
+    import random
+    rng = random.Random(77)
+    seqs = [bytes(rng.randrange(256) for _ in range(rng.choice([7, 100, 1000, 1500]))) for _ in range(600)]
+    seqs += [bytes([0]) * 1000, bytes([255]) * 999, bytes([0, 255] * 500)]
+    _check(ctx, O, seqs)
+
+
 def test_realistic_fixture_records(ctx, O):
     """676 real records (30..1342 nt, some with N) from the reference's nim_cated fixture."""
     recs = O.read_fasta(open(os.path.join(GOLDEN, "ref_examples", "nim_cated", "realistic_input.fasta"), "rb").read())
@@ -165,7 +174,7 @@ def test_device_generator_matches_host_generator(ctx, O):
     ctx.synth_fill_device(42, 12345, n, d)
     torch.cuda.synchronize()
     assert np.array_equal(d.cpu().numpy(), O.synth_fill(42, 12345, n))
-    ctx.set_stream(None)
+    ctx.use_own_stream()
 
 
 def test_full_size_properties_10m_x_1kb(ctx, O):
@@ -213,4 +222,4 @@ def test_full_size_properties_10m_x_1kb(ctx, O):
     assert torch.equal(c1[:N * L], c3[:N * L])
     # a strict strand decision flips with the input strand (ties = reverse palindromes keep strand 1)
     assert int(((strand + s3) != 1).sum().item()) <= 5
-    ctx.set_stream(None)
+    ctx.use_own_stream()
