@@ -38,16 +38,28 @@ CK_DEV void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-CK_DEV uint32_t wave_min_u32(uint32_t v)
+// min over each aligned row of 16 lanes, in every lane of the row: 4 DPP steps (xor 1, xor 2, half mirror,
+// mirror), no LDS crossbar traffic.
+CK_DEV uint32_t row_min16_u32(uint32_t v)
 {
-    // 6-step butterfly over 64 lanes; result in every lane.
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ m) << 2), (int)v);
-        v = o < v ? o : v;
-    }
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); v = o < v ? o : v;   // quad_perm [1,0,3,2]
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); v = o < v ? o : v;   // quad_perm [2,3,0,1]
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = o < v ? o : v;  // row_half_mirror
+    o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = o < v ? o : v;  // row_mirror
     return v;
 }
+// wave-wide min, wave-uniform result (lands in SGPRs): row mins by DPP, then 4 readlanes + scalar mins.
+CK_DEV uint32_t wave_min_u32(uint32_t v)
+{
+    v = row_min16_u32(v);
+    const uint32_t a = readlane(v, 0), b = readlane(v, 16), c = readlane(v, 32), d = readlane(v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+// low 32 bits of (hi:lo) >> s, s in 0..63
+CK_DEV uint32_t lshr64(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s); }
+CK_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }   // v_bfi_b32
 CK_DEV uint64_t wave_sum_u64(uint64_t v)
 {
 #pragma unroll
@@ -144,6 +156,15 @@ CK_DEV uint64_t wave_sum_u64(uint64_t v)
     uint64_t s = 0; for (int i = 0; i < 64; ++i) s += all[i];
     return s;
 }
+CK_DEV uint32_t row_min16_u32(uint32_t v)
+{
+    uint64_t all[64]; emu::gather(v, all);
+    const uint32_t base = lane_id() & ~15u;
+    uint32_t m = ~0u; for (uint32_t i = base; i < base + 16; ++i) m = (uint32_t)all[i] < m ? (uint32_t)all[i] : m;
+    return m;
+}
+CK_DEV uint32_t lshr64(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s); }
+CK_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
 CK_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {
     uint64_t src = ((uint64_t)s0 << 32) | s1;
