@@ -421,101 +421,6 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Fast path: pure-ACGT record of 48..1008 bases = at most 63 packed words, ONE WORD PER LANE, held in
-// registers; cross-lane access by ds_bpermute / v_readlane, reductions by DPP.  Straight-line code:
-// the only branches are the wave-uniform exits to the general path (non-ACGT byte, repeated minimum).
-// ------------------------------------------------------------------------------------------------
-// the 16 symbols at cyclic symbol position p (any lane-varying p < 2n) of a one-word-per-lane strand
-CK_DEV uint32_t reg_sym_word(uint32_t E, uint32_t p, uint32_t n)
-{
-    p = p >= n ? p - n : p;
-    const uint32_t wi = p >> 4, sh = (p & 15) * 2;
-    return lshr64(shfl(E, wi), shfl(E, wi + 1), 32 - sh);
-}
-
-// position of the unique minimal key, if it is unique among the valid positions
-CK_DEV bool fast2_locate(uint32_t E, uint32_t En, uint32_t m, uint32_t M, uint32_t n, uint32_t& pos)
-{
-    const uint32_t t = lane_id();
-    uint64_t hm = ballot(m == M);
-    if (popc64(hm) > 2) return false;
-    uint32_t cnt = 0;
-    while (hm) {
-        const uint32_t l = (uint32_t)ffs64(hm);
-        hm &= hm - 1;
-        const uint32_t cur = readlane(E, l), nxt = readlane(En, l);
-        const uint32_t b = t & 15;
-        const uint32_t k = lshr64(cur, nxt, 32 - 2 * b);
-        const uint64_t pm = ballot(t < 16 && k == M && 16 * l + b < n);
-        cnt += (uint32_t)popc64(pm);
-        if (pm) pos = 16 * l + (uint32_t)ffs64(pm);
-    }
-    return cnt == 1;
-}
-
-CK_DEV bool canon_fast2(const CanonArgs& a, uint64_t rec, const uint8_t* src, uint64_t off, uint32_t n)
-{
-    const uint32_t t = lane_id();
-    const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
-    // forward words; lanes >= nwf read the record's last 16 bytes (in bounds) and shift the r tail symbols up
-    const bool tail = t >= nwf;
-    uint32_t bad = 0;
-    uint32_t F = pack2_fwd(load16(src + (tail ? n - 16 : 16 * t)), bad);
-    if (ballot(bad != 0)) return false;
-    F <<= tail ? ((16 - r) & 15) * 2 : 0;
-    // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
-    {
-        const uint32_t A = shfl(F, t - nwv), B = shfl(F, t - nwv + 1);
-        const uint32_t ext = lshr64(A, B, 32 - ((16 - r) & 15) * 2);
-        const uint32_t fix = bfi(~(0xFFFFFFFFu >> (2 * r)), F, B >> (2 * r));
-        F = t >= nwv ? ext : (t == nwf ? fix : F);        // r == 0: nwf == nwv, `fix` is never selected
-    }
-    // reverse-complement strand from the extended forward words:
-    // rc word t = comp(reverse(forward symbols [n - 16(t+1), n - 16t) mod n))
-    uint32_t C;
-    {
-        const int32_t p0 = (int32_t)n - 16 * (int32_t)(t + 1);
-        const uint32_t p = (uint32_t)(p0 < 0 ? p0 + (int32_t)n : p0);
-        const uint32_t wi = p >> 4, sh = (p & 15) * 2;
-        const uint32_t g = ~lshr64(shfl(F, wi), shfl(F, wi + 1), 32 - sh);
-        const uint32_t v = bitrev(g);                       // reverses bits; swap the two bits of every symbol back
-        C = bfi(0x55555555u, v >> 1, v << 1);
-    }
-    const uint32_t Fn = shfl(F, t + 1), Cn = shfl(C, t + 1);
-    uint32_t mF = word_min_key<2>(F, Fn), mC = word_min_key<2>(C, Cn);
-    mF = t < nwv ? mF : ~0u;
-    mC = t < nwv ? mC : ~0u;
-    const uint32_t MF = wave_min_u32(mF), MC = wave_min_u32(mC);
-    uint32_t iF = 0, iC = 0;
-    if (!fast2_locate(F, Fn, mF, MF, n, iF)) return false;
-    const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
-    if (!fwd_only && !fast2_locate(C, Cn, mC, MC, n, iC)) return false;
-    // lexicographic select (lib/src/canonicalize.rs:58-62) on the two rotated strings, 16 symbols per lane
-    const uint32_t wa = reg_sym_word(F, iF + 16 * t, n);
-    const uint32_t wb = reg_sym_word(C, iC + 16 * t, n);
-    bool fwd = true;
-    if (!fwd_only) {
-        const uint32_t d = t < nwv ? (wa ^ wb) : 0u;
-        const uint64_t bal = ballot(d != 0);
-        fwd = false;
-        if (bal) {
-            const uint32_t l = (uint32_t)ffs64(bal);
-            const uint32_t k = 16 * l + (uint32_t)clz32(readlane(d, l)) / 2;
-            fwd = k < n && readlane(wa, l) < readlane(wb, l);
-        }
-    }
-    if (a.out_bytes && t < nwv) {
-        const uint32_t left = n - 16 * t;
-        store_bytes(a.out_bytes + off + 16 * t, decode2(fwd ? wa : wb), left < 16 ? left : 16);
-    }
-    if (t == 0) {
-        if (a.out_index) a.out_index[rec] = fwd ? iF : (iC + iF) % n;   // unique minimum => period n
-        if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
-    }
-    return true;
-}
-
 // Processes one record; returns false if it does not fit this tier's LDS slice.
 CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds)
 {
@@ -529,7 +434,6 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds)
         }
         return true;
     }
-    if (n >= 48 && n <= 1008 && canon_fast2(a, rec, src, off, n)) return true;
     if (n >= 48) {
         if (need_dw<2>(n) > a.slice_dw) return false;
         if (canon_record_mode<2>(a, rec, src, off, n, lds)) return true;

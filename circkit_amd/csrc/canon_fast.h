@@ -1,0 +1,151 @@
+// canon_fast.h -- the streaming kernel of the canonicalize path.
+//
+// Handles the records that make up BASELINE's headline workload -- pure ACGT, 48..1008 bases -- with one
+// packed word per lane held in REGISTERS (no LDS memory; cross-lane access by ds_bpermute / v_readlane,
+// reductions by DPP), straight-line code, and a software pipeline that has the next record's bytes and
+// the record after that's offsets in flight while the current one is computed.  Anything else (other
+// alphabets, longer or shorter records, a repeated minimal key) is appended to a list for the general
+// LDS kernel of canon_core.h.  Same reference functions as there (lib/src/canonicalize.rs:5-63).
+#pragma once
+#include "canon_core.h"
+
+namespace ck {
+
+constexpr uint32_t FAST_MIN_N = 48, FAST_MAX_N = 1008;
+
+// the 16 symbols at cyclic symbol position p (lane-varying, p < 2n) of a one-word-per-lane strand
+CK_DEV uint32_t reg_sym_word(uint32_t E, uint32_t p, uint32_t n)
+{
+    p = p >= n ? p - n : p;
+    const uint32_t wi = p >> 4, sh = (p & 15) * 2;
+    return lshr64(shfl(E, wi), shfl(E, wi + 1), 32 - sh);
+}
+
+// position of the minimal key M if exactly one valid position owns it.  shv = 32 - 2*(lane & 15).
+CK_DEV bool fast2_locate(uint32_t E, uint32_t En, uint32_t m, uint32_t M, uint32_t n, uint32_t shv, uint32_t& pos)
+{
+    const uint32_t t = lane_id();
+    uint64_t hm = ballot(m == M);
+    if (popc64(hm) > 2) return false;
+    uint32_t cnt = 0;
+    while (hm) {        // 1 iteration; 2 when the minimum sits in the first 16 - n%16 positions (duplicate behind the end)
+        const uint32_t l = (uint32_t)ffs64(hm);
+        hm &= hm - 1;
+        const uint32_t k = lshr64(readlane(E, l), readlane(En, l), shv);
+        const uint32_t left = n - 16 * l;                                   // valid positions in word l
+        const uint64_t pm = ballot(k == M && t < (left < 16 ? left : 16));
+        cnt += (uint32_t)popc64(pm);
+        if (pm) pos = 16 * l + (uint32_t)ffs64(pm);
+    }
+    return cnt == 1;
+}
+
+struct FastRec {
+    uint64_t off;
+    uint32_t n;
+    bool eligible;
+    u32x4 v;        // this lane's 16 input bytes
+};
+
+CK_DEV void fast_issue(const CanonArgs& a, uint64_t off, uint64_t end, FastRec& r)
+{
+    r.off = off;
+    r.n = (uint32_t)(end - off);
+    r.eligible = (end - off) >= FAST_MIN_N && (end - off) <= FAST_MAX_N;
+    r.v = u32x4{ 0, 0, 0, 0 };
+    if (r.eligible) {
+        const uint32_t t = lane_id();
+        // lanes >= n/16 read the record's last 16 bytes (in bounds) and shift the n%16 tail symbols up later
+        r.v = load16(a.bytes + off + (t >= (r.n >> 4) ? r.n - 16 : 16 * t));
+    }
+}
+
+// returns false when the record must go to the general kernel
+CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, const FastRec& in)
+{
+    if (!in.eligible) return false;
+    const uint32_t t = lane_id(), n = in.n;
+    const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
+    uint32_t bad = 0;
+    uint32_t F = pack2_fwd(in.v, bad);
+    if (ballot(bad != 0)) return false;
+    F <<= t >= nwf ? ((16 - r) & 15) * 2 : 0;
+    // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
+    {
+        const uint32_t A = shfl(F, t - nwv), B = shfl(F, t - nwv + 1);
+        const uint32_t ext = lshr64(A, B, 32 - ((16 - r) & 15) * 2);
+        const uint32_t fix = bfi(~(0xFFFFFFFFu >> (2 * r)), F, B >> (2 * r));
+        F = t >= nwv ? ext : (t == nwf ? fix : F);        // r == 0: nwf == nwv, `fix` is never selected
+    }
+    const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
+    // reverse-complement strand from the extended forward words:
+    // rc word t = comp(reverse(forward symbols [n - 16(t+1), n - 16t) mod n))
+    uint32_t C;
+    {
+        const int32_t p0 = (int32_t)n - 16 * (int32_t)(t + 1);
+        const uint32_t p = (uint32_t)(p0 < 0 ? p0 + (int32_t)n : p0);
+        const uint32_t g = ~lshr64(shfl(F, p >> 4), shfl(F, (p >> 4) + 1), 32 - (p & 15) * 2);
+        const uint32_t v = bitrev(g);                       // reverses bits; swap the two bits of every symbol back
+        C = bfi(0x55555555u, v >> 1, v << 1);
+    }
+    const uint32_t Fn = shfl(F, t + 1), Cn = shfl(C, t + 1);
+    uint32_t mF = word_min_key<2>(F, Fn), mC = word_min_key<2>(C, Cn);
+    mF = t < nwv ? mF : ~0u;
+    mC = t < nwv ? mC : ~0u;
+    uint32_t MF, MC;
+    wave_min2_u32(mF, mC, MF, MC);
+    const uint32_t shv = 32 - 2 * (t & 15);
+    uint32_t iF = 0, iC = 0;
+    if (!fast2_locate(F, Fn, mF, MF, n, shv, iF)) return false;
+    if (!fwd_only && !fast2_locate(C, Cn, mC, MC, n, shv, iC)) return false;
+    // lexicographic select (lib/src/canonicalize.rs:58-62).  The minimal keys ARE the first 16 symbols of
+    // the two minimal rotations, so they decide unless equal; only then compare the full rotations.
+    bool fwd = fwd_only || MF < MC;
+    if (!fwd_only && MF == MC) {
+        const uint32_t wa = reg_sym_word(F, iF + 16 * t, n), wb = reg_sym_word(C, iC + 16 * t, n);
+        const uint32_t d = t < nwv ? (wa ^ wb) : 0u;
+        const uint64_t bal = ballot(d != 0);
+        if (bal) {
+            const uint32_t l = (uint32_t)ffs64(bal);
+            const uint32_t k = 16 * l + (uint32_t)clz32(readlane(d, l)) / 2;
+            fwd = k < n && readlane(wa, l) < readlane(wb, l);
+        }
+    }
+    if (a.out_bytes) {
+        const uint32_t w = reg_sym_word(fwd ? F : C, (fwd ? iF : iC) + 16 * t, n);
+        if (t < nwv) {
+            const uint32_t left = n - 16 * t;
+            store_bytes(a.out_bytes + in.off + 16 * t, decode2(w), left < 16 ? left : 16);
+        }
+    }
+    if (t == 0) {
+        // unique minimum => period n; iC + iF < 2n
+        if (a.out_index) a.out_index[rec] = fwd ? iF : (iC + iF >= n ? iC + iF - n : iC + iF);
+        if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+    }
+    return true;
+}
+
+// Software-pipelined grid-stride loop of one wave: while record k is computed, the bytes of record
+// k + stride and the offsets of record k + 2*stride are already in flight.
+CK_DEV void canon_fast_wave_loop(const CanonArgs& a, uint32_t wave_id, uint32_t n_waves)
+{
+    const uint64_t total = a.n_records, stride = n_waves;
+    uint64_t rec = wave_id;
+    if (rec >= total) return;
+    FastRec cur, nxt;
+    fast_issue(a, a.offsets[rec], a.offsets[rec + 1], cur);
+    uint64_t o0 = 0, o1 = 0;
+    if (rec + stride < total) { o0 = a.offsets[rec + stride]; o1 = a.offsets[rec + stride + 1]; }
+    for (; rec < total; rec += stride) {
+        const bool has_next = rec + stride < total;
+        nxt = cur;
+        if (has_next) fast_issue(a, o0, o1, nxt);
+        if (rec + 2 * stride < total) { o0 = a.offsets[rec + 2 * stride]; o1 = a.offsets[rec + 2 * stride + 1]; }
+        if (!fast_process(a, rec, cur) && lane_id() == 0)
+            a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
+        cur = nxt;
+    }
+}
+
+}  // namespace ck

@@ -9,6 +9,7 @@
 
 #include "../../include/circkit.h"
 #include "canon_core.h"
+#include "canon_fast.h"
 #include "xxh3_core.h"
 
 namespace {
@@ -25,6 +26,13 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     const uint32_t wave = ck::uniform(blockIdx.x * WPB + wib);
     ck::canon_wave_loop(a, lds + wib * a.slice_dw, wave, gridDim.x * WPB);
+}
+
+// The streaming kernel (canon_fast.h): registers only, no LDS allocation, 8 workgroups of 4 waves per CU.
+__global__ __launch_bounds__(256) void canon_fast_kernel(ck::CanonArgs a)
+{
+    const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    ck::canon_fast_wave_loop(a, wave, gridDim.x * 4);
 }
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).
@@ -144,8 +152,9 @@ struct circkit_ctx {
     bool timed = false;
     std::string err;
     uint8_t* d_comp = nullptr;
-    uint32_t* d_counters = nullptr;      // [0],[1] deferred counts of tiers A,B; [2] unprocessed; [3] uniq overflow
-    uint32_t* d_list_a = nullptr;        // deferred lists
+    uint32_t* d_counters = nullptr;      // [0..2] deferred counts of fast kernel, tiers A,B; [3] unprocessed; [4] uniq overflow
+    uint32_t* d_list_f = nullptr;        // deferred lists: fast kernel -> tier A -> tier B -> tier C
+    uint32_t* d_list_a = nullptr;
     uint32_t* d_list_b = nullptr;
     uint64_t list_cap = 0;
     // host-batch staging (grow only)
@@ -178,9 +187,11 @@ int fail(circkit_ctx* c, int code, const char* fmt, ...)
 int ensure_lists(circkit_ctx* c, uint64_t n)
 {
     if (n <= c->list_cap) return CIRCKIT_OK;
+    if (c->d_list_f) { (void)hipFree(c->d_list_f); c->d_list_f = nullptr; }
     if (c->d_list_a) { (void)hipFree(c->d_list_a); c->d_list_a = nullptr; }
     if (c->d_list_b) { (void)hipFree(c->d_list_b); c->d_list_b = nullptr; }
     c->list_cap = 0;
+    CK_HIP(c, hipMalloc(&c->d_list_f, n * sizeof(uint32_t)));
     CK_HIP(c, hipMalloc(&c->d_list_a, n * sizeof(uint32_t)));
     CK_HIP(c, hipMalloc(&c->d_list_b, n * sizeof(uint32_t)));
     c->list_cap = n;
@@ -195,31 +206,29 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     int rc = ensure_lists(c, n);
     if (rc) return rc;
-    CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 3 * sizeof(uint32_t), c->stream));
+    CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr;
-    a.comp_lut = c->d_comp; a.status = c->d_counters + 2; a.flags = flags;
-    // tier A over every record
-    a.list = nullptr; a.list_count = nullptr; a.defer_list = c->d_list_a; a.defer_count = c->d_counters + 0;
+    a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
+    const uint64_t blocks = (n + 3) / 4;
+    const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
+    // streaming kernel over every record; what it cannot take goes down the LDS tiers
+    a.list = nullptr; a.list_count = nullptr; a.defer_list = c->d_list_f; a.defer_count = c->d_counters + 0;
+    a.slice_dw = 0;
+    hipLaunchKernelGGL(canon_fast_kernel, dim3(grid), dim3(256), 0, c->stream, a);
+    a.list = c->d_list_f; a.list_count = c->d_counters + 0; a.defer_list = c->d_list_a; a.defer_count = c->d_counters + 1;
     a.slice_dw = TIER_A_DW;
-    {
-        const uint64_t blocks = (n + 3) / 4;
-        const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
-        hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), 4 * TIER_A_DW * 4, c->stream, a);
-    }
-    // tier B over what A deferred, tier C over what B deferred (both exit at once on empty lists)
-    a.list = c->d_list_a; a.list_count = c->d_counters + 0; a.defer_list = c->d_list_b; a.defer_count = c->d_counters + 1;
+    hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), 4 * TIER_A_DW * 4, c->stream, a);
+    a.list = c->d_list_a; a.list_count = c->d_counters + 1; a.defer_list = c->d_list_b; a.defer_count = c->d_counters + 2;
     a.slice_dw = TIER_B_DW;
     hipLaunchKernelGGL(canon_kernel<1>, dim3(N_CU * 4), dim3(64), TIER_B_DW * 4, c->stream, a);
-    a.list = c->d_list_b; a.list_count = c->d_counters + 1; a.defer_list = nullptr; a.defer_count = nullptr;
+    a.list = c->d_list_b; a.list_count = c->d_counters + 2; a.defer_list = nullptr; a.defer_count = nullptr;
     a.slice_dw = TIER_C_DW;
     hipLaunchKernelGGL(canon_kernel<1>, dim3(N_CU), dim3(64), TIER_C_DW * 4, c->stream, a);
     if (d_hash) {
         if (!d_out) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_out_xxh3 currently needs d_out_bytes");
-        const uint64_t blocks = (n + 3) / 4;
-        const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
         hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash);
     }
     CK_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -281,7 +290,7 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     if (strand) CK_HIP(c, hipMemcpyAsync(strand, c->d_strand, n, hipMemcpyDeviceToHost, c->stream));
     if (hash) CK_HIP(c, hipMemcpyAsync(hash, c->d_hash, n * 8, hipMemcpyDeviceToHost, c->stream));
     uint32_t unprocessed = 0;
-    CK_HIP(c, hipMemcpyAsync(&unprocessed, c->d_counters + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipMemcpyAsync(&unprocessed, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
     if (unprocessed)
         return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) exceed the largest LDS tier and were not processed", unprocessed);
@@ -331,7 +340,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     if (!c) return CIRCKIT_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* ptrs[] = { c->d_comp, c->d_counters, c->d_list_a, c->d_list_b, c->d_in, c->d_out, c->d_strand, c->d_off,
+    void* ptrs[] = { c->d_comp, c->d_counters, c->d_list_f, c->d_list_a, c->d_list_b, c->d_in, c->d_out, c->d_strand, c->d_off,
                      c->d_idx, c->d_hash, c->d_keys, c->d_vals };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -378,7 +387,7 @@ int circkit_ctx_batch_status(circkit_ctx* c, uint32_t* n_unprocessed)
 {
     if (!c || !n_unprocessed) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
-    CK_HIP(c, hipMemcpyAsync(n_unprocessed, c->d_counters + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipMemcpyAsync(n_unprocessed, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
     return *n_unprocessed ? CIRCKIT_ERR_TOO_LONG : CIRCKIT_OK;
 }
@@ -490,7 +499,7 @@ int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
     }
     hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_keys, cap + 1, (unsigned long long)UNIQ_EMPTY);
     hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_vals, cap + 1, (unsigned long long)UNIQ_EMPTY);
-    CK_HIP(c, hipMemsetAsync(c->d_counters + 3, 0, 4, c->stream));
+    CK_HIP(c, hipMemsetAsync(c->d_counters + 4, 0, 4, c->stream));
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
 }
@@ -502,7 +511,7 @@ int circkit_uniq_insert_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, base_index, c->d_keys,
-                       c->d_vals, c->uniq_mask, c->d_counters + 3);
+                       c->d_vals, c->uniq_mask, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
 }
@@ -517,7 +526,7 @@ int circkit_uniq_lookup_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
                        c->uniq_mask, d_first_seen);
     CK_HIP(c, hipGetLastError());
     uint32_t overflow = 0;
-    CK_HIP(c, hipMemcpyAsync(&overflow, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipMemcpyAsync(&overflow, c->d_counters + 4, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
     if (overflow) return fail(c, CIRCKIT_ERR_OOM, "uniq table overflow: more distinct keys than circkit_uniq_reset sized it for");
     return CIRCKIT_OK;

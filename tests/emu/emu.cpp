@@ -90,6 +90,7 @@ void run_wave(void (*body)(void*), void* arg)
 }}  // namespace ck::emu
 
 #include "../../circkit_amd/csrc/canon_core.h"
+#include "../../circkit_amd/csrc/canon_fast.h"
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
@@ -99,24 +100,37 @@ void wave_body(void* p)
     Launch* L = (Launch*)p;
     ck::canon_wave_loop(L->a, L->lds, L->wave_id, L->n_waves);
 }
+void fast_body(void* p)
+{
+    Launch* L = (Launch*)p;
+    ck::canon_fast_wave_loop(L->a, L->wave_id, L->n_waves);
+}
 }
 
 extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                       uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
                                       uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
-                                      uint32_t* n_deferred, uint32_t flags)
+                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast)
 {
     uint8_t comp[256];
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
     const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
-    std::vector<uint32_t> lds(slice_dw + 16), deferred(n_records + 1);
-    uint32_t defer_count = 0, status = 0;
+    // same launch sequence as the host library: streaming kernel over everything, then the LDS tier
+    std::vector<uint32_t> lds(slice_dw + 16), list_f(n_records + 1), deferred(n_records + 1);
+    uint32_t count_f = 0, defer_count = 0, status = 0;
     Launch L;
     L.a = ck::CanonArgs{ bytes, offsets, n_records, out_bytes, out_index, out_strand, out_hash,
-                         nullptr, nullptr, deferred.data(), &defer_count, &status, comp, slice_dw, flags };
+                         nullptr, nullptr, list_f.data(), &count_f, &status, comp, 0, flags };
     L.lds = lds.data();
     L.n_waves = n_waves;
+    for (uint32_t w = 0; w < n_waves; ++w) {
+        L.wave_id = w;
+        ck::emu::run_wave(fast_body, &L);
+    }
+    if (n_fast) *n_fast = (uint32_t)n_records - count_f;
+    L.a.list = list_f.data(); L.a.list_count = &count_f;
+    L.a.defer_list = deferred.data(); L.a.defer_count = &defer_count; L.a.slice_dw = slice_dw;
     for (uint32_t w = 0; w < n_waves; ++w) {
         L.wave_id = w;
         ck::emu::run_wave(wave_body, &L);

@@ -80,3 +80,13 @@ def test_lmsr_forward_only_flag():
         a, b = int(offs[i]), int(offs[i + 1])
         assert out[a:b].tobytes() == O.lmsr(s)
         assert int(idx[i]) == O.lmsr_index(s) and int(strand[i]) == 0
+
+
+def test_streaming_kernel_takes_the_headline_records():
+    """Pure-ACGT 1 kb records must be handled by the register-resident streaming kernel, not the LDS tier."""
+    seqs = seqsets.random_mixed(35, 64, 1000, 1000)
+    data, offs = seqsets.pack(seqs)
+    emu.canonicalize_batch(data, offs)
+    assert emu.last_fast_count == len(seqs)
+    emu.canonicalize_batch(*seqsets.pack([b"ACGTN" * 200, b"A" * 500, b"ACGT" * 10, b"ACGT" * 300]))
+    assert emu.last_fast_count == 0     # N, repeats, too short, too long -> general kernel
