@@ -40,34 +40,31 @@ CK_DEV bool fast2_locate(uint32_t E, uint32_t En, uint32_t m, uint32_t M, uint32
     return cnt == 1;
 }
 
-struct FastRec {
-    uint64_t off;
-    uint32_t n;
-    bool eligible;
-    u32x4 v;        // this lane's 16 input bytes
-};
-
-CK_DEV void fast_issue(const CanonArgs& a, uint64_t off, uint64_t end, FastRec& r)
+// Issue the LDS-DMA prefetch of a record: lane t's 16 input bytes land at buf + 16t.  Eligible record:
+// lanes >= n/16 fetch the record's last 16 bytes (in bounds, n >= 48); their n%16 tail symbols are shifted
+// up later.  Other records: a dummy fetch of the offsets array (always >= 16 readable bytes), so that every
+// call issues exactly one vector-memory instruction -- the pipeline's vmcnt bookkeeping depends on it.
+CK_DEV bool fast_issue(const CanonArgs& a, uint64_t off, uint64_t end, uint32_t* buf)
 {
-    r.off = off;
-    r.n = (uint32_t)(end - off);
-    r.eligible = (end - off) >= FAST_MIN_N && (end - off) <= FAST_MAX_N;
-    r.v = u32x4{ 0, 0, 0, 0 };
-    if (r.eligible) {
-        const uint32_t t = lane_id();
-        // lanes >= n/16 read the record's last 16 bytes (in bounds) and shift the n%16 tail symbols up later
-        r.v = load16(a.bytes + off + (t >= (r.n >> 4) ? r.n - 16 : 16 * t));
-    }
+    const bool ok = end - off >= FAST_MIN_N && end - off <= FAST_MAX_N;
+    const uint32_t t = lane_id(), n = (uint32_t)(end - off);
+    const uint8_t* src = ok ? a.bytes + off + (t >= (n >> 4) ? n - 16 : 16 * t) : (const uint8_t*)a.offsets;
+    glds16_async(buf, src);
+    return ok;
+}
+CK_DEV u32x4 fast_fetch(const uint32_t* buf)
+{
+    const uint32_t* p = buf + 4 * lane_id();
+    return u32x4{ p[0], p[1], p[2], p[3] };
 }
 
 // returns false when the record must go to the general kernel
-CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, const FastRec& in)
+CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, uint64_t off, uint32_t n, u32x4 bytes)
 {
-    if (!in.eligible) return false;
-    const uint32_t t = lane_id(), n = in.n;
+    const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
     uint32_t bad = 0;
-    uint32_t F = pack2_fwd(in.v, bad);
+    uint32_t F = pack2_fwd(bytes, bad);
     if (ballot(bad != 0)) return false;
     F <<= t >= nwf ? ((16 - r) & 15) * 2 : 0;
     // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
@@ -112,11 +109,11 @@ CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, const FastRec& in)
         }
     }
     if (a.out_bytes) {
-        const uint32_t w = reg_sym_word(fwd ? F : C, (fwd ? iF : iC) + 16 * t, n);
-        if (t < nwv) {
-            const uint32_t left = n - 16 * t;
-            store_bytes(a.out_bytes + in.off + 16 * t, decode2(w), left < 16 ? left : 16);
-        }
+        // every lane stores a full 16 bytes: the last lane's window is pulled back to end exactly at n, so it
+        // overlaps its neighbour's with identical bytes -- one store instruction, no partial-store branches
+        const uint32_t o = 16 * t + 16 <= n ? 16 * t : n - 16;
+        const uint32_t w = reg_sym_word(fwd ? F : C, (fwd ? iF : iC) + o, n);
+        if (t < nwv) store16(a.out_bytes + off + o, decode2(w));
     }
     if (t == 0) {
         // unique minimum => period n; iC + iF < 2n
@@ -126,25 +123,45 @@ CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, const FastRec& in)
     return true;
 }
 
-// Software-pipelined grid-stride loop of one wave: while record k is computed, the bytes of record
-// k + stride and the offsets of record k + 2*stride are already in flight.
-CK_DEV void canon_fast_wave_loop(const CanonArgs& a, uint32_t wave_id, uint32_t n_waves)
+// Software-pipelined grid-stride loop of one wave over two 1 KiB LDS buffers (lds[0..255], lds[256..511]):
+// while record k is computed, the bytes of record k + stride are in flight (LDS-DMA) and so are the offsets
+// of record k + 2*stride (scalar load, lgkmcnt).  vmcnt bookkeeping: between the DMA of a record and the
+// point its bytes are needed, the only younger vector-memory instructions are the previous record's stores
+// -- at least one when canonical bytes are written (the 16-byte store, or the defer-list store), possibly
+// none otherwise -- so the wait is vmcnt(1) resp. vmcnt(0).
+CK_DEV void canon_fast_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t wave_id, uint32_t n_waves)
 {
     const uint64_t total = a.n_records, stride = n_waves;
     uint64_t rec = wave_id;
     if (rec >= total) return;
-    FastRec cur, nxt;
-    fast_issue(a, a.offsets[rec], a.offsets[rec + 1], cur);
-    uint64_t o0 = 0, o1 = 0;
-    if (rec + stride < total) { o0 = a.offsets[rec + stride]; o1 = a.offsets[rec + stride + 1]; }
-    for (; rec < total; rec += stride) {
-        const bool has_next = rec + stride < total;
-        nxt = cur;
-        if (has_next) fast_issue(a, o0, o1, nxt);
-        if (rec + 2 * stride < total) { o0 = a.offsets[rec + 2 * stride]; o1 = a.offsets[rec + 2 * stride + 1]; }
-        if (!fast_process(a, rec, cur) && lane_id() == 0)
+    uint32_t* bufA = lds;
+    uint32_t* bufB = lds + 256;
+    const bool stores = a.out_bytes != nullptr;
+    uint64_t offA = a.offsets[rec], endA = a.offsets[rec + 1], offB = 0, endB = 0;
+    bool okA = fast_issue(a, offA, endA, bufA), okB = false;
+    vmem_wait<0>();
+    ck_u32x4v sq = sload_u64x2(a.offsets + (rec + stride < total ? rec + stride : rec));
+    for (;;) {
+        // ---- A computes, B loads
+        sload_wait(sq, offB, endB);
+        const bool hasB = rec + stride < total;
+        okB = fast_issue(a, offB, endB, bufB) && hasB;
+        sq = sload_u64x2(a.offsets + (rec + 2 * stride < total ? rec + 2 * stride : rec));
+        if (!(okA && fast_process(a, rec, offA, (uint32_t)(endA - offA), fast_fetch(bufA))) && lane_id() == 0)
             a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
-        cur = nxt;
+        if (stores) vmem_wait<1>(); else vmem_wait<0>();
+        rec += stride;
+        if (!hasB) break;
+        // ---- B computes, A loads
+        sload_wait(sq, offA, endA);
+        const bool hasA = rec + stride < total;
+        okA = fast_issue(a, offA, endA, bufA) && hasA;
+        sq = sload_u64x2(a.offsets + (rec + 2 * stride < total ? rec + 2 * stride : rec));
+        if (!(okB && fast_process(a, rec, offB, (uint32_t)(endB - offB), fast_fetch(bufB))) && lane_id() == 0)
+            a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
+        if (stores) vmem_wait<1>(); else vmem_wait<0>();
+        rec += stride;
+        if (!hasA) break;
     }
 }
 

@@ -28,11 +28,13 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
     ck::canon_wave_loop(a, lds + wib * a.slice_dw, wave, gridDim.x * WPB);
 }
 
-// The streaming kernel (canon_fast.h): registers only, no LDS allocation, 8 workgroups of 4 waves per CU.
+// The streaming kernel (canon_fast.h): packed words in registers, 2 KiB of LDS per wave for the record prefetch.
 __global__ __launch_bounds__(256) void canon_fast_kernel(ck::CanonArgs a)
 {
-    const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    ck::canon_fast_wave_loop(a, wave, gridDim.x * 4);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 512];      // two 1 KiB prefetch buffers per wave
+    const uint32_t wib = ck::uniform(threadIdx.x >> 6);
+    const uint32_t wave = ck::uniform(blockIdx.x * 4 + wib);
+    ck::canon_fast_wave_loop(a, lds + wib * 512, wave, gridDim.x * 4);
 }
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).

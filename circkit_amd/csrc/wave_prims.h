@@ -141,6 +141,41 @@ CK_DEV uint32_t load4(const uint8_t* p)
 }
 CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 
+// Two consecutive u64 (a CSR offset pair) through the scalar cache: s_load_dwordx4, tracked by lgkmcnt, so
+// it never forces a vmcnt(0) that would drain the prefetched record bytes.  p must be wave-uniform and the
+// memory read-only for the kernel's lifetime.  The load is asynchronous: call sload_wait() before use.
+typedef uint32_t ck_u32x4v __attribute__((ext_vector_type(4)));
+// LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at
+// lds_dst + 16*lane (global_load_lds_dwordx4; M0 carries the wave-uniform LDS base).  No VGPR destination,
+// so the compiler cannot touch the data before it lands; completion is OUR bookkeeping: vmem_wait<N>(),
+// N = vector-memory instructions issued after this one that may still be outstanding (vmcnt counts loads,
+// stores and LDS-DMA together, in issue order).  Used by the software pipeline of canon_fast.h, where
+// hipcc's own waitcnt insertion degrades to vmcnt(0) and would drain the prefetch.
+CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc)
+{
+    uint32_t keep;
+    const uint32_t dst = (uint32_t)(uintptr_t)lds_dst;     // low 32 bits of an LDS generic address = LDS offset
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+template <int N>
+CK_DEV void vmem_wait()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+CK_DEV ck_u32x4v sload_u64x2(const uint64_t* p)
+{
+    ck_u32x4v r;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+CK_DEV void sload_wait(ck_u32x4v& r, uint64_t& a, uint64_t& b)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r) :: "memory");
+    a = ((uint64_t)r.y << 32) | r.x;
+    b = ((uint64_t)r.w << 32) | r.z;
+}
+
 }  // namespace ck
 
 #else
@@ -232,6 +267,19 @@ CK_DEV void store8(uint8_t* p, uint32_t a, uint32_t b) { memcpy(p, &a, 4); memcp
 CK_DEV void store4(uint8_t* p, uint32_t a) { memcpy(p, &a, 4); }
 CK_DEV uint32_t load4(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+struct ck_u32x4v { uint32_t x, y, z, w; };
+CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), gsrc, 16); }
+template <int N>
+CK_DEV void vmem_wait() {}
+CK_DEV ck_u32x4v sload_u64x2(const uint64_t* p)
+{
+    ck_u32x4v r; memcpy(&r, p, 16); return r;
+}
+CK_DEV void sload_wait(ck_u32x4v& r, uint64_t& a, uint64_t& b)
+{
+    a = ((uint64_t)r.y << 32) | r.x;
+    b = ((uint64_t)r.w << 32) | r.z;
+}
 
 }  // namespace ck
 #endif
