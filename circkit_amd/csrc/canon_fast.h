@@ -58,14 +58,49 @@ CK_DEV u32x4 fast_fetch(const uint32_t* buf)
     return u32x4{ p[0], p[1], p[2], p[3] };
 }
 
+// 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); `bad` = wave mask of lanes holding a byte
+// that is not A/C/G/T.  Validity = the check LUT reproduces the dword; four ballots keep it at one v_cmp_ne
+// per dword with the ORs on the scalar unit.
+CK_DEV uint32_t fast_pack(u32x4 v, uint64_t& bad)
+{
+    const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+    uint32_t u[4];
+    bad = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sel = (d[k] >> 1) & HASH_MASK;
+        bad |= ballot(perm(0u, CHK2_LO, sel) != d[k]);
+        const uint32_t code = perm(0u, 0x02030100u, sel);
+        const uint32_t t = code | (code << 10);
+        u[k] = t | (t << 20);
+    }
+    return perm(u[0], u[1], 0x07030c0cu) | perm(u[2], u[3], 0x0c0c0703u);
+}
+
+// 256-entry LDS table: packed byte (4 symbols, first in the top bits) -> its 4 ASCII bytes.  Replaces ~6 VALU
+// per output dword (spread the 2-bit fields into bytes, v_perm) by shift + mask + one ds_read_b32.
+CK_DEV void fast_lut_init(uint32_t* lut, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t x = tid; x < 256; x += nthreads) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o |= ((0x54474341u >> (8 * ((x >> (6 - 2 * k)) & 3))) & 0xFFu) << (8 * k);
+        lut[x] = o;
+    }
+}
+CK_DEV u32x4 fast_decode(const uint32_t* lut, uint32_t w)
+{
+    return u32x4{ lut[w >> 24], lut[(w >> 16) & 0xFF], lut[(w >> 8) & 0xFF], lut[w & 0xFF] };
+}
+
 // returns false when the record must go to the general kernel
-CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, uint64_t off, uint32_t n, u32x4 bytes)
+CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint64_t rec, uint64_t off, uint32_t n, u32x4 bytes)
 {
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
-    uint32_t bad = 0;
-    uint32_t F = pack2_fwd(bytes, bad);
-    if (ballot(bad != 0)) return false;
+    uint64_t bad;
+    uint32_t F = fast_pack(bytes, bad);
+    if (bad) return false;
     F <<= t >= nwf ? ((16 - r) & 15) * 2 : 0;
     // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
     {
@@ -113,7 +148,7 @@ CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, uint64_t off, uint32_
         // overlaps its neighbour's with identical bytes -- one store instruction, no partial-store branches
         const uint32_t o = 16 * t + 16 <= n ? 16 * t : n - 16;
         const uint32_t w = reg_sym_word(fwd ? F : C, (fwd ? iF : iC) + o, n);
-        if (t < nwv) store16(a.out_bytes + off + o, decode2(w));
+        if (t < nwv) store16(a.out_bytes + off + o, fast_decode(lut, w));
     }
     if (t == 0) {
         // unique minimum => period n; iC + iF < 2n
@@ -129,7 +164,7 @@ CK_DEV bool fast_process(const CanonArgs& a, uint64_t rec, uint64_t off, uint32_
 // point its bytes are needed, the only younger vector-memory instructions are the previous record's stores
 // -- at least one when canonical bytes are written (the 16-byte store, or the defer-list store), possibly
 // none otherwise -- so the wait is vmcnt(1) resp. vmcnt(0).
-CK_DEV void canon_fast_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t wave_id, uint32_t n_waves)
+CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* lds, uint32_t wave_id, uint32_t n_waves)
 {
     const uint64_t total = a.n_records, stride = n_waves;
     uint64_t rec = wave_id;
@@ -147,7 +182,7 @@ CK_DEV void canon_fast_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t wav
         const bool hasB = rec + stride < total;
         okB = fast_issue(a, offB, endB, bufB) && hasB;
         sq = sload_u64x2(a.offsets + (rec + 2 * stride < total ? rec + 2 * stride : rec));
-        if (!(okA && fast_process(a, rec, offA, (uint32_t)(endA - offA), fast_fetch(bufA))) && lane_id() == 0)
+        if (!(okA && fast_process(a, lut, rec, offA, (uint32_t)(endA - offA), fast_fetch(bufA))) && lane_id() == 0)
             a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
         if (stores) vmem_wait<1>(); else vmem_wait<0>();
         rec += stride;
@@ -157,7 +192,7 @@ CK_DEV void canon_fast_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t wav
         const bool hasA = rec + stride < total;
         okA = fast_issue(a, offA, endA, bufA) && hasA;
         sq = sload_u64x2(a.offsets + (rec + 2 * stride < total ? rec + 2 * stride : rec));
-        if (!(okB && fast_process(a, rec, offB, (uint32_t)(endB - offB), fast_fetch(bufB))) && lane_id() == 0)
+        if (!(okB && fast_process(a, lut, rec, offB, (uint32_t)(endB - offB), fast_fetch(bufB))) && lane_id() == 0)
             a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
         if (stores) vmem_wait<1>(); else vmem_wait<0>();
         rec += stride;

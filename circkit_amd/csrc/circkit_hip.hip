@@ -31,10 +31,12 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
 // The streaming kernel (canon_fast.h): packed words in registers, 2 KiB of LDS per wave for the record prefetch.
 __global__ __launch_bounds__(256) void canon_fast_kernel(ck::CanonArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 512];      // two 1 KiB prefetch buffers per wave
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 512 + 256];   // two 1 KiB prefetch buffers per wave + decode table
+    ck::fast_lut_init(lds + 4 * 512, threadIdx.x, 256);
+    __syncthreads();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + wib);
-    ck::canon_fast_wave_loop(a, lds + wib * 512, wave, gridDim.x * 4);
+    ck::canon_fast_wave_loop(a, lds + 4 * 512, lds + wib * 512, wave, gridDim.x * 4);
 }
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).

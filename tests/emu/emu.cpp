@@ -94,7 +94,7 @@ void run_wave(void (*body)(void*), void* arg)
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; uint32_t wave_id, n_waves; };
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t wave_id, n_waves; };
 void wave_body(void* p)
 {
     Launch* L = (Launch*)p;
@@ -103,7 +103,7 @@ void wave_body(void* p)
 void fast_body(void* p)
 {
     Launch* L = (Launch*)p;
-    ck::canon_fast_wave_loop(L->a, L->lds, L->wave_id, L->n_waves);
+    ck::canon_fast_wave_loop(L->a, L->lut, L->lds, L->wave_id, L->n_waves);
 }
 }
 
@@ -123,6 +123,9 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a = ck::CanonArgs{ bytes, offsets, n_records, out_bytes, out_index, out_strand, out_hash,
                          nullptr, nullptr, list_f.data(), &count_f, &status, comp, 0, flags };
     L.lds = lds.data();
+    uint32_t lut[256];
+    ck::fast_lut_init(lut, 0, 1);
+    L.lut = lut;
     L.n_waves = n_waves;
     for (uint32_t w = 0; w < n_waves; ++w) {
         L.wave_id = w;
