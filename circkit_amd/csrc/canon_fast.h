@@ -21,36 +21,41 @@ CK_DEV uint32_t reg_sym_word(uint32_t E, uint32_t p, uint32_t n)
     return lshr64(shfl(E, wi), shfl(E, wi + 1), 32 - sh);
 }
 
-// position of the minimal key M if exactly one valid position owns it.  shv = 32 - 2*(lane & 15).
-CK_DEV bool fast2_locate(uint32_t E, uint32_t En, uint32_t m, uint32_t M, uint32_t n, uint32_t shv, uint32_t& pos)
+// Position of the minimal key M, and whether exactly one valid position owns it.  hm = lanes whose word
+// minimum equals M.  Straight-line for the common single-hit case; a second hit (the duplicate of word 0's
+// first positions behind the record end, or a real tie) takes one extra round; more hits = not unique.
+// shv = 32 - 2*(lane & 15).
+CK_DEV uint32_t fast2_locate(uint32_t E, uint32_t En, uint64_t hm, uint32_t M, uint32_t n, uint32_t shv, bool& unique)
 {
-    const uint32_t t = lane_id();
-    uint64_t hm = ballot(m == M);
-    if (popc64(hm) > 2) return false;
-    uint32_t cnt = 0;
-    while (hm) {        // 1 iteration; 2 when the minimum sits in the first 16 - n%16 positions (duplicate behind the end)
-        const uint32_t l = (uint32_t)ffs64(hm);
-        hm &= hm - 1;
-        const uint32_t k = lshr64(readlane(E, l), readlane(En, l), shv);
-        const uint32_t left = n - 16 * l;                                   // valid positions in word l
-        const uint64_t pm = ballot(k == M && t < (left < 16 ? left : 16));
-        cnt += (uint32_t)popc64(pm);
-        if (pm) pos = 16 * l + (uint32_t)ffs64(pm);
+    const uint32_t l = (uint32_t)ffs64(hm | (1ull << 63));
+    const uint32_t k = lshr64(readlane(E, l), readlane(En, l), shv);
+    const uint32_t left = n - 16 * l;                                       // valid positions in word l
+    uint64_t pm = ballot(k == M) & ((left < 16 ? (1ull << left) : 0x10000ull) - 1);
+    uint32_t cnt = (uint32_t)popc64(pm);
+    uint32_t pos = 16 * l + (uint32_t)ffs64(pm | (1ull << 63));
+    hm &= hm - 1;
+    if (hm) {                                                               // rare
+        const uint32_t l2 = (uint32_t)ffs64(hm);
+        const uint32_t k2 = lshr64(readlane(E, l2), readlane(En, l2), shv);
+        const uint32_t left2 = n - 16 * l2;
+        const uint64_t pm2 = ballot(k2 == M) & ((left2 < 16 ? (1ull << left2) : 0x10000ull) - 1);
+        cnt += (uint32_t)popc64(pm2) + ((hm & (hm - 1)) ? 2u : 0u);         // a third hit lane: give up
+        if (pm == 0) pos = 16 * l2 + (uint32_t)ffs64(pm2 | (1ull << 63));
     }
-    return cnt == 1;
+    unique = cnt == 1;
+    return pos;
 }
 
 // Issue the LDS-DMA prefetch of a record: lane t's 16 input bytes land at buf + 16t.  Eligible record:
 // lanes >= n/16 fetch the record's last 16 bytes (in bounds, n >= 48); their n%16 tail symbols are shifted
 // up later.  Other records: a dummy fetch of the offsets array (always >= 16 readable bytes), so that every
 // call issues exactly one vector-memory instruction -- the pipeline's vmcnt bookkeeping depends on it.
-CK_DEV bool fast_issue(const CanonArgs& a, uint64_t off, uint64_t end, uint32_t* buf)
+CK_DEV bool fast_eligible(uint32_t n) { return n - FAST_MIN_N <= FAST_MAX_N - FAST_MIN_N; }
+CK_DEV void fast_issue(const CanonArgs& a, uint64_t off, uint32_t n, uint32_t* buf)
 {
-    const bool ok = end - off >= FAST_MIN_N && end - off <= FAST_MAX_N;
-    const uint32_t t = lane_id(), n = (uint32_t)(end - off);
-    const uint8_t* src = ok ? a.bytes + off + (t >= (n >> 4) ? n - 16 : 16 * t) : (const uint8_t*)a.offsets;
+    const uint32_t t = lane_id();
+    const uint8_t* src = fast_eligible(n) ? a.bytes + off + (t >= (n >> 4) ? n - 16 : 16 * t) : (const uint8_t*)a.offsets;
     glds16_async(buf, src);
-    return ok;
 }
 CK_DEV u32x4 fast_fetch(const uint32_t* buf)
 {
@@ -93,14 +98,16 @@ CK_DEV u32x4 fast_decode(const uint32_t* lut, uint32_t w)
     return u32x4{ lut[w >> 24], lut[(w >> 16) & 0xFF], lut[(w >> 8) & 0xFF], lut[w & 0xFF] };
 }
 
-// returns false when the record must go to the general kernel
-CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint64_t rec, uint64_t off, uint32_t n, u32x4 bytes)
+// Canonicalizes one eligible record held as 16 bytes per lane; returns false (nothing written) when the
+// record must go to the general kernel: a byte outside ACGT, or a minimal key that is not unique.
+// Single exit: the rare failures are folded into one flag instead of early returns, which keeps the
+// scalar unit's branch / mask bookkeeping off the hot path.
+CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uint64_t off, uint32_t n, u32x4 bytes)
 {
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
     uint64_t bad;
     uint32_t F = fast_pack(bytes, bad);
-    if (bad) return false;
     F <<= t >= nwf ? ((16 - r) & 15) * 2 : 0;
     // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
     {
@@ -115,27 +122,29 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint64_t rec, 
     uint32_t C;
     {
         const int32_t p0 = (int32_t)n - 16 * (int32_t)(t + 1);
-        const uint32_t p = (uint32_t)(p0 < 0 ? p0 + (int32_t)n : p0);
+        const uint32_t p = (uint32_t)(p0 + ((p0 >> 31) & (int32_t)n));
         const uint32_t g = ~lshr64(shfl(F, p >> 4), shfl(F, (p >> 4) + 1), 32 - (p & 15) * 2);
         const uint32_t v = bitrev(g);                       // reverses bits; swap the two bits of every symbol back
         C = bfi(0x55555555u, v >> 1, v << 1);
     }
-    const uint32_t Fn = shfl(F, t + 1), Cn = shfl(C, t + 1);
+    const uint32_t Fn = wave_shl1(F), Cn = wave_shl1(C);
     uint32_t mF = word_min_key<2>(F, Fn), mC = word_min_key<2>(C, Cn);
-    mF = t < nwv ? mF : ~0u;
-    mC = t < nwv ? mC : ~0u;
+    const bool valid = t < nwv;
+    mF = valid ? mF : ~0u;
+    mC = valid ? mC : ~0u;
     uint32_t MF, MC;
     wave_min2_u32(mF, mC, MF, MC);
     const uint32_t shv = 32 - 2 * (t & 15);
-    uint32_t iF = 0, iC = 0;
-    if (!fast2_locate(F, Fn, mF, MF, n, shv, iF)) return false;
-    if (!fwd_only && !fast2_locate(C, Cn, mC, MC, n, shv, iC)) return false;
+    bool uF, uC;
+    const uint32_t iF = fast2_locate(F, Fn, ballot(mF == MF), MF, n, shv, uF);
+    const uint32_t iC = fast2_locate(C, Cn, ballot(mC == MC), MC, n, shv, uC);
+    if (bad != 0 || !uF || !(uC || fwd_only)) return false;
     // lexicographic select (lib/src/canonicalize.rs:58-62).  The minimal keys ARE the first 16 symbols of
     // the two minimal rotations, so they decide unless equal; only then compare the full rotations.
     bool fwd = fwd_only || MF < MC;
     if (!fwd_only && MF == MC) {
         const uint32_t wa = reg_sym_word(F, iF + 16 * t, n), wb = reg_sym_word(C, iC + 16 * t, n);
-        const uint32_t d = t < nwv ? (wa ^ wb) : 0u;
+        const uint32_t d = valid ? (wa ^ wb) : 0u;
         const uint64_t bal = ballot(d != 0);
         if (bal) {
             const uint32_t l = (uint32_t)ffs64(bal);
@@ -148,7 +157,7 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint64_t rec, 
         // overlaps its neighbour's with identical bytes -- one store instruction, no partial-store branches
         const uint32_t o = 16 * t + 16 <= n ? 16 * t : n - 16;
         const uint32_t w = reg_sym_word(fwd ? F : C, (fwd ? iF : iC) + o, n);
-        if (t < nwv) store16(a.out_bytes + off + o, fast_decode(lut, w));
+        if (valid) store16(a.out_bytes + off + o, fast_decode(lut, w));
     }
     if (t == 0) {
         // unique minimum => period n; iC + iF < 2n
@@ -158,45 +167,61 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint64_t rec, 
     return true;
 }
 
-// Software-pipelined grid-stride loop of one wave over two 1 KiB LDS buffers (lds[0..255], lds[256..511]):
-// while record k is computed, the bytes of record k + stride are in flight (LDS-DMA) and so are the offsets
-// of record k + 2*stride (scalar load, lgkmcnt).  vmcnt bookkeeping: between the DMA of a record and the
-// point its bytes are needed, the only younger vector-memory instructions are the previous record's stores
-// -- at least one when canonical bytes are written (the 16-byte store, or the defer-list store), possibly
-// none otherwise -- so the wait is vmcnt(1) resp. vmcnt(0).
+// Software-pipelined grid-stride loop of one wave over a ring of three 1 KiB LDS buffers: while record k
+// is computed, the bytes of records k + stride and k + 2*stride are in flight (LDS-DMA, 2 KiB per wave,
+// 64 KiB per CU) and so are the offsets of record k + 3*stride (scalar load, lgkmcnt).
+// vmcnt bookkeeping: every step issues exactly one DMA.  When record k+1's bytes are needed (end of step k)
+// the vector-memory instructions younger than its DMA are: the stores of record k-1, the DMA of k+2, the
+// stores of record k.  A record stores at least once when canonical bytes are written (the 16-byte store,
+// or the defer-list store), possibly never otherwise: wait vmcnt(3) resp. vmcnt(1).
+struct FastSlot { uint64_t off; uint32_t n; };
+
+CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uint32_t last, uint32_t stride,
+                      const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill, uint32_t* fill_buf, ck_u32x4v& sq)
+{
+    // the offsets of record min(rec + 2*stride, last) were requested one step ago: DMA it into the free buffer
+    uint64_t o0, o1;
+    sload_wait(sq, o0, o1);
+    fill.off = o0;
+    fill.n = (uint32_t)(o1 - o0);
+    fast_issue(a, o0, fill.n, fill_buf);
+    const uint32_t r3 = rec + 3 * stride;
+    sq = sload_u64x2(a.offsets + (r3 < last ? r3 : last));
+    if (!(fast_eligible(cur.n) && fast_process(a, lut, rec, cur.off, cur.n, fast_fetch(cur_buf))) && lane_id() == 0)
+        a.defer_list[atomic_add_u32(a.defer_count, 1u)] = rec;
+    if (a.out_bytes) vmem_wait<3>(); else vmem_wait<1>();
+}
+
 CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* lds, uint32_t wave_id, uint32_t n_waves)
 {
-    const uint64_t total = a.n_records, stride = n_waves;
-    uint64_t rec = wave_id;
+    // record indices fit 32 bits (n_records < 2^32 is an ABI precondition); prefetches past the end re-fetch
+    // the last record (harmless, keeps one DMA per step)
+    const uint32_t total = (uint32_t)a.n_records, stride = n_waves, last = total - 1;
+    uint32_t rec = wave_id;
     if (rec >= total) return;
-    uint32_t* bufA = lds;
-    uint32_t* bufB = lds + 256;
-    const bool stores = a.out_bytes != nullptr;
-    uint64_t offA = a.offsets[rec], endA = a.offsets[rec + 1], offB = 0, endB = 0;
-    bool okA = fast_issue(a, offA, endA, bufA), okB = false;
-    vmem_wait<0>();
-    ck_u32x4v sq = sload_u64x2(a.offsets + (rec + stride < total ? rec + stride : rec));
+    uint32_t* b0 = lds;
+    uint32_t* b1 = lds + 256;
+    uint32_t* b2 = lds + 512;
+    FastSlot s0, s1, s2;
+    {   // prologue: records rec and rec + stride
+        const uint32_t r1 = rec + stride < last ? rec + stride : last;
+        const uint64_t p0 = a.offsets[rec], p1 = a.offsets[rec + 1], q0 = a.offsets[r1], q1 = a.offsets[r1 + 1];
+        s0.off = p0; s0.n = (uint32_t)(p1 - p0); fast_issue(a, p0, s0.n, b0);
+        s1.off = q0; s1.n = (uint32_t)(q1 - q0); fast_issue(a, q0, s1.n, b1);
+        vmem_wait<1>();
+    }
+    const uint32_t r2 = rec + 2 * stride;
+    ck_u32x4v sq = sload_u64x2(a.offsets + (r2 < last ? r2 : last));
     for (;;) {
-        // ---- A computes, B loads
-        sload_wait(sq, offB, endB);
-        const bool hasB = rec + stride < total;
-        okB = fast_issue(a, offB, endB, bufB) && hasB;
-        sq = sload_u64x2(a.offsets + (rec + 2 * stride < total ? rec + 2 * stride : rec));
-        if (!(okA && fast_process(a, lut, rec, offA, (uint32_t)(endA - offA), fast_fetch(bufA))) && lane_id() == 0)
-            a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
-        if (stores) vmem_wait<1>(); else vmem_wait<0>();
+        fast_step(a, lut, rec, last, stride, s0, b0, s2, b2, sq);
         rec += stride;
-        if (!hasB) break;
-        // ---- B computes, A loads
-        sload_wait(sq, offA, endA);
-        const bool hasA = rec + stride < total;
-        okA = fast_issue(a, offA, endA, bufA) && hasA;
-        sq = sload_u64x2(a.offsets + (rec + 2 * stride < total ? rec + 2 * stride : rec));
-        if (!(okB && fast_process(a, lut, rec, offB, (uint32_t)(endB - offB), fast_fetch(bufB))) && lane_id() == 0)
-            a.defer_list[atomic_add_u32(a.defer_count, 1u)] = (uint32_t)rec;
-        if (stores) vmem_wait<1>(); else vmem_wait<0>();
+        if (rec >= total) break;
+        fast_step(a, lut, rec, last, stride, s1, b1, s0, b0, sq);
         rec += stride;
-        if (!hasA) break;
+        if (rec >= total) break;
+        fast_step(a, lut, rec, last, stride, s2, b2, s1, b1, sq);
+        rec += stride;
+        if (rec >= total) break;
     }
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -28,15 +29,15 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
     ck::canon_wave_loop(a, lds + wib * a.slice_dw, wave, gridDim.x * WPB);
 }
 
-// The streaming kernel (canon_fast.h): packed words in registers, 2 KiB of LDS per wave for the record prefetch.
+// The streaming kernel (canon_fast.h): packed words in registers, 3 KiB of LDS per wave for the record prefetch ring.
 __global__ __launch_bounds__(256) void canon_fast_kernel(ck::CanonArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 512 + 256];   // two 1 KiB prefetch buffers per wave + decode table
-    ck::fast_lut_init(lds + 4 * 512, threadIdx.x, 256);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 768 + 256];   // three 1 KiB prefetch buffers per wave + decode table
+    ck::fast_lut_init(lds + 4 * 768, threadIdx.x, 256);
     __syncthreads();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + wib);
-    ck::canon_fast_wave_loop(a, lds + 4 * 512, lds + wib * 512, wave, gridDim.x * 4);
+    ck::canon_fast_wave_loop(a, lds + 4 * 768, lds + wib * 768, wave, gridDim.x * 4);
 }
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).
@@ -154,6 +155,7 @@ struct circkit_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    uint32_t debug_flags = 0;            // CIRCKIT_DEBUG_FLAGS: timing ablations of the streaming kernel (bits 8..)
     std::string err;
     uint8_t* d_comp = nullptr;
     uint32_t* d_counters = nullptr;      // [0..2] deferred counts of fast kernel, tiers A,B; [3] unprocessed; [4] uniq overflow
@@ -205,7 +207,7 @@ int ensure_lists(circkit_ctx* c, uint64_t n)
 int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out,
                  uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags)
 {
-    if (n >= (1ull << 32)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^32");
+    if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     int rc = ensure_lists(c, n);
@@ -215,7 +217,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr;
-    a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
+    a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags | c->debug_flags;
     const uint64_t blocks = (n + 3) / 4;
     const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
@@ -319,6 +321,7 @@ int circkit_ctx_create(int device, circkit_ctx** out)
         return CIRCKIT_ERR_NO_DEVICE;
     circkit_ctx* c = new circkit_ctx();
     c->device = device;
+    if (const char* e = getenv("CIRCKIT_DEBUG_FLAGS")) c->debug_flags = (uint32_t)strtoul(e, nullptr, 0) << 8;
     *out = c;   // handed out even on failure below so the caller can read last_error, then destroy
     CK_HIP(c, hipSetDevice(device));
     CK_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));

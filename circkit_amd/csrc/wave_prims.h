@@ -57,6 +57,13 @@ CK_DEV uint32_t wave_min_u32(uint32_t v)
     const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
     return ab < cd ? ab : cd;
 }
+// lane i <- lane i+1 (lane 63 <- 0): DPP wave_shl:1, one VALU op instead of a ds_bpermute round trip.
+CK_DEV uint32_t wave_shl1(uint32_t v)
+{
+    uint32_t o;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(o) : "v"(v));
+    return o;
+}
 // Two independent wave-wide mins at once.  The two DPP chains are interleaved so each fills the other's
 // VALU->DPP wait states (2 needed; one comes from the sibling instruction, one from s_nop 0) and the
 // min is fused into the DPP instruction (hipcc emits v_mov_dpp + v_min otherwise).
@@ -77,11 +84,17 @@ CK_DEV void wave_min2_u32(uint32_t x, uint32_t y, uint32_t& mx, uint32_t& my)
         "v_min_u32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1"
         : "+v"(x), "+v"(y));
-    const uint32_t a0 = readlane(x, 0), a1 = readlane(x, 16), a2 = readlane(x, 32), a3 = readlane(x, 48);
-    const uint32_t b0 = readlane(y, 0), b1 = readlane(y, 16), b2 = readlane(y, 32), b3 = readlane(y, 48);
-    const uint32_t a01 = a0 < a1 ? a0 : a1, a23 = a2 < a3 ? a2 : a3, b01 = b0 < b1 ? b0 : b1, b23 = b2 < b3 ? b2 : b3;
-    mx = a01 < a23 ? a01 : a23;
-    my = b01 < b23 ? b01 : b23;
+    // rows 1,3 take min with lane 15 of rows 0,2; rows 2,3 take min with lane 31: lane 63 = wave min
+    asm volatile(
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x), "+v"(y));
+    mx = readlane(x, 63);
+    my = readlane(y, 63);
 }
 // low 32 bits of (hi:lo) >> s, s in 0..63
 CK_DEV uint32_t lshr64(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s); }
@@ -216,6 +229,11 @@ CK_DEV uint64_t wave_sum_u64(uint64_t v)
     uint64_t all[64]; emu::gather(v, all);
     uint64_t s = 0; for (int i = 0; i < 64; ++i) s += all[i];
     return s;
+}
+CK_DEV uint32_t wave_shl1(uint32_t v)
+{
+    uint64_t all[64]; emu::gather(v, all);
+    return lane_id() < 63 ? (uint32_t)all[lane_id() + 1] : 0u;
 }
 CK_DEV void wave_min2_u32(uint32_t x, uint32_t y, uint32_t& mx, uint32_t& my)
 {

@@ -69,7 +69,7 @@ int circkit_ctx_last_kernel_ms(circkit_ctx* ctx, float* ms);
  *                lmsr_index(revcomp(lmsr(s))) -- the two indices the reference computes (:43, :56)
  *   d_out_strand nullable; uint8[n_records]: 0 = lmsr(s) returned, 1 = lmsr(revcomp) returned (:58-62)
  *   d_out_xxh3   nullable; uint64[n_records]: XXH3-64 (seed 0) of the canonical sequence
- * n_records must be < 2^32 and every record shorter than 2^31 bytes. */
+ * n_records must be < 2^31 and every record shorter than 2^31 bytes. */
 int circkit_canonicalize_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                                       uint64_t n_records, uint8_t* d_out_bytes, uint32_t* d_out_index,
                                       uint8_t* d_out_strand, uint64_t* d_out_xxh3);
