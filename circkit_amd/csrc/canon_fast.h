@@ -167,61 +167,64 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint32_t rec, 
     return true;
 }
 
-// Software-pipelined grid-stride loop of one wave over a ring of three 1 KiB LDS buffers: while record k
-// is computed, the bytes of records k + stride and k + 2*stride are in flight (LDS-DMA, 2 KiB per wave,
-// 64 KiB per CU) and so are the offsets of record k + 3*stride (scalar load, lgkmcnt).
-// vmcnt bookkeeping: every step issues exactly one DMA.  When record k+1's bytes are needed (end of step k)
-// the vector-memory instructions younger than its DMA are: the stores of record k-1, the DMA of k+2, the
-// stores of record k.  A record stores at least once when canonical bytes are written (the 16-byte store,
-// or the defer-list store), possibly never otherwise: wait vmcnt(3) resp. vmcnt(1).
+// Software-pipelined grid-stride loop of one wave over a ring of NB 1 KiB LDS buffers: while record k is
+// computed, the bytes of records k + stride .. k + (NB-1)*stride are in flight (LDS-DMA) and so are the
+// offsets of record k + NB*stride (scalar load, lgkmcnt).  Memory-level parallelism is what the copy
+// microbenchmark (tools/microbench/copy_bench.hip) shows this chip needs: one 1 KiB request per wave tops
+// out near 4.2 TB/s, several in flight reach 5.4+.
+// vmcnt bookkeeping: every step issues exactly one DMA (depth D = NB-1 ahead).  When record k+1's bytes
+// are needed (end of step k) the vector-memory instructions younger than its DMA are the stores of the last
+// D records and the DMAs of the last D-1 steps.  A record stores at least once when canonical bytes are
+// written (the 16-byte store, or the defer-list store), possibly never otherwise: wait vmcnt(2D-1) resp.
+// vmcnt(D-1).
 struct FastSlot { uint64_t off; uint32_t n; };
 
+template <int NB>
 CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uint32_t last, uint32_t stride,
                       const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill, uint32_t* fill_buf, ck_u32x4v& sq)
 {
-    // the offsets of record min(rec + 2*stride, last) were requested one step ago: DMA it into the free buffer
+    constexpr int D = NB - 1;
+    // the offsets of record min(rec + D*stride, last) were requested one step ago: DMA it into the free buffer
     uint64_t o0, o1;
     sload_wait(sq, o0, o1);
     fill.off = o0;
     fill.n = (uint32_t)(o1 - o0);
     fast_issue(a, o0, fill.n, fill_buf);
-    const uint32_t r3 = rec + 3 * stride;
-    sq = sload_u64x2(a.offsets + (r3 < last ? r3 : last));
+    const uint32_t rn = rec + NB * stride;
+    sq = sload_u64x2(a.offsets + (rn < last ? rn : last));
     if (!(fast_eligible(cur.n) && fast_process(a, lut, rec, cur.off, cur.n, fast_fetch(cur_buf))) && lane_id() == 0)
         a.defer_list[atomic_add_u32(a.defer_count, 1u)] = rec;
-    if (a.out_bytes) vmem_wait<3>(); else vmem_wait<1>();
+    if (a.out_bytes) vmem_wait<2 * D - 1>(); else vmem_wait<D - 1>();
 }
 
+template <int NB>
 CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* lds, uint32_t wave_id, uint32_t n_waves)
 {
-    // record indices fit 32 bits (n_records < 2^32 is an ABI precondition); prefetches past the end re-fetch
+    // record indices fit 32 bits (n_records < 2^31 is an ABI precondition); prefetches past the end re-fetch
     // the last record (harmless, keeps one DMA per step)
     const uint32_t total = (uint32_t)a.n_records, stride = n_waves, last = total - 1;
     uint32_t rec = wave_id;
     if (rec >= total) return;
-    uint32_t* b0 = lds;
-    uint32_t* b1 = lds + 256;
-    uint32_t* b2 = lds + 512;
-    FastSlot s0, s1, s2;
-    {   // prologue: records rec and rec + stride
-        const uint32_t r1 = rec + stride < last ? rec + stride : last;
-        const uint64_t p0 = a.offsets[rec], p1 = a.offsets[rec + 1], q0 = a.offsets[r1], q1 = a.offsets[r1 + 1];
-        s0.off = p0; s0.n = (uint32_t)(p1 - p0); fast_issue(a, p0, s0.n, b0);
-        s1.off = q0; s1.n = (uint32_t)(q1 - q0); fast_issue(a, q0, s1.n, b1);
-        vmem_wait<1>();
+    FastSlot s[NB];
+#pragma unroll
+    for (int i = 0; i < NB - 1; ++i) {      // prologue: records rec .. rec + (NB-2)*stride
+        const uint32_t ri = rec + i * stride < last ? rec + i * stride : last;
+        const uint64_t p0 = a.offsets[ri], p1 = a.offsets[ri + 1];
+        s[i].off = p0; s[i].n = (uint32_t)(p1 - p0);
+        fast_issue(a, p0, s[i].n, lds + 256 * i);
     }
-    const uint32_t r2 = rec + 2 * stride;
-    ck_u32x4v sq = sload_u64x2(a.offsets + (r2 < last ? r2 : last));
+    vmem_wait<NB - 2>();
+    const uint32_t rp = rec + (NB - 1) * stride;
+    ck_u32x4v sq = sload_u64x2(a.offsets + (rp < last ? rp : last));
     for (;;) {
-        fast_step(a, lut, rec, last, stride, s0, b0, s2, b2, sq);
-        rec += stride;
-        if (rec >= total) break;
-        fast_step(a, lut, rec, last, stride, s1, b1, s0, b0, sq);
-        rec += stride;
-        if (rec >= total) break;
-        fast_step(a, lut, rec, last, stride, s2, b2, s1, b1, sq);
-        rec += stride;
-        if (rec >= total) break;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            constexpr int dummy = 0; (void)dummy;
+            const int f = (i + NB - 1) % NB;
+            fast_step<NB>(a, lut, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f, sq);
+            rec += stride;
+            if (rec >= total) return;
+        }
     }
 }
 

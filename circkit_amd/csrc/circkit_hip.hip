@@ -11,6 +11,15 @@
 #include "../../include/circkit.h"
 #include "canon_core.h"
 #include "canon_fast.h"
+#ifndef CK_FAST_NB
+#define CK_FAST_NB 3
+#endif
+#ifndef CK_FAST_WPE
+#define CK_FAST_WPE 1     // min waves per SIMD the streaming kernel is compiled for
+#endif
+#ifndef CK_FAST_BPC
+#define CK_FAST_BPC 16    // workgroups launched per CU (6 resident; the rest queue and smooth the tail)
+#endif
 #include "xxh3_core.h"
 
 namespace {
@@ -29,15 +38,17 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
     ck::canon_wave_loop(a, lds + wib * a.slice_dw, wave, gridDim.x * WPB);
 }
 
-// The streaming kernel (canon_fast.h): packed words in registers, 3 KiB of LDS per wave for the record prefetch ring.
-__global__ __launch_bounds__(256) void canon_fast_kernel(ck::CanonArgs a)
+// The streaming kernel (canon_fast.h): packed words in registers, a ring of FAST_NB 1 KiB LDS buffers per wave
+// for the record prefetch, plus the 1 KiB decode table per workgroup.
+constexpr int FAST_NB = CK_FAST_NB;
+__global__ __launch_bounds__(256, CK_FAST_WPE) void canon_fast_kernel(ck::CanonArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 768 + 256];   // three 1 KiB prefetch buffers per wave + decode table
-    ck::fast_lut_init(lds + 4 * 768, threadIdx.x, 256);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 256 * FAST_NB + 256];
+    ck::fast_lut_init(lds + 4 * 256 * FAST_NB, threadIdx.x, 256);
     __syncthreads();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + wib);
-    ck::canon_fast_wave_loop(a, lds + 4 * 768, lds + wib * 768, wave, gridDim.x * 4);
+    ck::canon_fast_wave_loop<FAST_NB>(a, lds + 4 * 256 * FAST_NB, lds + wib * 256 * FAST_NB, wave, gridDim.x * 4);
 }
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).
@@ -223,7 +234,10 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
     a.list = nullptr; a.list_count = nullptr; a.defer_list = c->d_list_f; a.defer_count = c->d_counters + 0;
     a.slice_dw = 0;
-    hipLaunchKernelGGL(canon_fast_kernel, dim3(grid), dim3(256), 0, c->stream, a);
+    {
+        const unsigned fgrid = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
+        hipLaunchKernelGGL(canon_fast_kernel, dim3(fgrid), dim3(256), 0, c->stream, a);
+    }
     a.list = c->d_list_f; a.list_count = c->d_counters + 0; a.defer_list = c->d_list_a; a.defer_count = c->d_counters + 1;
     a.slice_dw = TIER_A_DW;
     hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), 4 * TIER_A_DW * 4, c->stream, a);

@@ -103,7 +103,7 @@ void wave_body(void* p)
 void fast_body(void* p)
 {
     Launch* L = (Launch*)p;
-    ck::canon_fast_wave_loop(L->a, L->lut, L->lds, L->wave_id, L->n_waves);
+    ck::canon_fast_wave_loop<4>(L->a, L->lut, L->lds, L->wave_id, L->n_waves);
 }
 }
 
@@ -117,7 +117,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
     // same launch sequence as the host library: streaming kernel over everything, then the LDS tier
-    std::vector<uint32_t> lds((slice_dw > 768 ? slice_dw : 768) + 16), list_f(n_records + 1), deferred(n_records + 1);
+    std::vector<uint32_t> lds((slice_dw > 1024 ? slice_dw : 1024) + 16), list_f(n_records + 1), deferred(n_records + 1);
     uint32_t count_f = 0, defer_count = 0, status = 0;
     Launch L;
     L.a = ck::CanonArgs{ bytes, offsets, n_records, out_bytes, out_index, out_strand, out_hash,
