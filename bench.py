@@ -22,6 +22,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
+def pmc_traffic(n_records, length):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
+    (profiles/traffic.json; bench.py cannot collect PMC counters itself).  None if the profile is for
+    another workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if t.get("workload") == "canonicalize %d x %d" % (n_records, length):
+            return t["traffic_bytes"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,8 +127,8 @@ def main():
                        "records_per_gpu": N, "record_len": L,
                        "parallelism": "records sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "canon_kernel<4>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(N, L),
+                         "kernel": "canon_fast_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
         }
         if world == 1 and not args.no_cpu:
             from oracle import oracle as O
