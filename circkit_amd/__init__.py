@@ -5,3 +5,4 @@ api.py     ctypes mirror of the reference's lib-crate API over that C ABI
 """
 from .api import (CirckitError, Context, canonicalize, default_context, lmsr, lmsr_index, load_library, normalize,  # noqa: F401
                   xxh3_64)
+from . import uniq  # noqa: F401,E402

@@ -178,6 +178,7 @@ struct circkit_ctx {
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_strand = nullptr;
     uint64_t* d_off = nullptr; uint32_t* d_idx = nullptr; uint64_t* d_hash = nullptr;
     uint64_t cap_bytes = 0, cap_rec = 0;
+    uint8_t* d_scratch = nullptr; uint64_t cap_scratch = 0;   // canonical bytes of hash-only batches
     // uniq table
     unsigned long long *d_keys = nullptr, *d_vals = nullptr;
     uint64_t uniq_mask = 0;
@@ -223,6 +224,21 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     int rc = ensure_lists(c, n);
     if (rc) return rc;
+    if (d_hash && !d_out) {
+        // hash-only (uniq without --canonicalize): the canonical bytes go to a ctx-owned scratch the hash kernel
+        // reads back.  Its size is offsets[n] - offsets[0], fetched from the device (one small synchronous copy).
+        uint64_t first = 0, lastoff = 0;
+        CK_HIP(c, hipMemcpyAsync(&first, d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
+        CK_HIP(c, hipMemcpyAsync(&lastoff, d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
+        CK_HIP(c, hipStreamSynchronize(c->stream));
+        if (lastoff + 64 > c->cap_scratch) {
+            if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->cap_scratch = 0; }
+            CK_HIP(c, hipMalloc(&c->d_scratch, lastoff + 64));
+            c->cap_scratch = lastoff + 64;
+        }
+        d_out = c->d_scratch;       // indexed by the same absolute offsets as the input
+        (void)first;
+    }
     CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
@@ -248,7 +264,6 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.slice_dw = TIER_C_DW;
     hipLaunchKernelGGL(canon_kernel<1>, dim3(N_CU), dim3(64), TIER_C_DW * 4, c->stream, a);
     if (d_hash) {
-        if (!d_out) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_out_xxh3 currently needs d_out_bytes");
         hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash);
     }
     CK_HIP(c, hipEventRecord(c->ev1, c->stream));
@@ -362,7 +377,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void* ptrs[] = { c->d_comp, c->d_counters, c->d_list_f, c->d_list_a, c->d_list_b, c->d_in, c->d_out, c->d_strand, c->d_off,
-                     c->d_idx, c->d_hash, c->d_keys, c->d_vals };
+                     c->d_idx, c->d_hash, c->d_keys, c->d_vals, c->d_scratch };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

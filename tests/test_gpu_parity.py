@@ -223,3 +223,66 @@ def test_full_size_properties_10m_x_1kb(ctx, O):
     # a strict strand decision flips with the input strand (ties = reverse palindromes keep strand 1)
     assert int(((strand + s3) != 1).sum().item()) <= 5
     ctx.use_own_stream()
+
+
+def _make_dups(rng, base_seqs, n_dups):
+    from tests import seqsets
+    out = list(base_seqs)
+    for _ in range(n_dups):
+        s = base_seqs[rng.randrange(len(base_seqs))]
+        k = rng.randrange(len(s)) if s else 0
+        d = s[k:] + s[:k]
+        if rng.random() < 0.5:
+            d = seqsets.revcomp_acgt(d)
+        out.append(d)
+    rng.shuffle(out)
+    return out
+
+
+def test_uniq_config3_shape(ctx, O):
+    """BASELINE config 3 at a size the oracle finishes in seconds: base records + ~50 % rotational / strand
+    duplicates, shuffled.  Hash-only device batch -> device hash table -> first-seen == src/uniq.rs semantics."""
+    import random
+    import torch
+    from circkit_amd import uniq
+    from tests import seqsets
+    rng = random.Random(43)
+    base = seqsets.random_mixed(43, 3000, 1000, 1000) + seqsets.random_mixed(44, 500, 30, 3000) + [b"", b"A", b"ACGTN" * 50]
+    seqs = _make_dups(rng, base, 3500)
+    data, offs = seqsets.pack(seqs)
+    n = len(seqs)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+    d_bytes[:len(data)] = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_hash = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.canonicalize_batch_device(d_bytes, d_off, n, out_xxh3=d_hash)          # hash-only mode
+    assert ctx.batch_status() == 0
+    _, exp_h = O.canonicalize_batch(data, offs, False, True, threads=8)
+    assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    fs, keep = uniq.first_seen(uniq.DeviceTable(ctx), d_hash, base_index=0)
+    exp_fs = O.uniq_first_seen(exp_h)
+    assert np.array_equal(fs.cpu().numpy().astype(np.uint64), exp_fs)
+    assert int(keep.sum().item()) == len({O.canonicalize(s) for s in base})
+    # streaming batches with a running base index fold into the same table
+    ctx.uniq_reset(n)
+    half = n // 2
+    ctx.uniq_insert_device(d_hash[:half].contiguous(), half, 0)
+    ctx.uniq_insert_device(d_hash[half:].contiguous(), n - half, half)
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.uniq_lookup_device(d_hash, n, out)
+    assert np.array_equal(out.cpu().numpy().astype(np.uint64), exp_fs)
+    ctx.use_own_stream()
+
+
+def test_uniq_repeated_fixture(ctx, O):
+    """tests/examples/repeated: five records, one survivor (tests/canon_uniq.rs:45)."""
+    import circkit_amd
+    recs = O.read_fasta(open(os.path.join(GOLDEN, "ref_examples", "repeated", "in.fasta"), "rb").read())
+    seqs = [circkit_amd.normalize(s)[0] for _, s in recs]
+    from tests import seqsets
+    data, offs = seqsets.pack(seqs)
+    got = ctx.canonicalize_batch(data, offs, want_xxh3=True)
+    assert len(set(got["xxh3"].tolist())) == 1
+    assert got["bytes"][:8].tobytes() == b"AAAAAAAT"
