@@ -41,6 +41,14 @@ SIGNATURES = {
     "circkit_uniq_reset": (_i, [_vp, _u64]),
     "circkit_uniq_insert_device": (_i, [_vp, _vp, _u64, _u64]),
     "circkit_uniq_lookup_device": (_i, [_vp, _vp, _u64, _vp]),
+    "circkit_uniq_first_seen": (_i, [_vp, _vp, _u64, _u64, _vp]),
+    "circkit_fasta_parse": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
+    "circkit_fasta_error": (ctypes.c_char_p, [_vp]),
+    "circkit_fasta_n_records": (_u64, [_vp]),
+    "circkit_fasta_bytes": (_vp, [_vp]),
+    "circkit_fasta_offsets": (_vp, [_vp]),
+    "circkit_fasta_record": (_i, [_vp, _u64] + [ctypes.POINTER(_sz)] * 4),
+    "circkit_fasta_free": (None, [_vp]),
     "circkit_synth_fill_device": (_i, [_vp, _u64, _u64, _u64, _vp]),
     "circkit_fixed_offsets_device": (_i, [_vp, _u64, _u64, _u64, _vp]),
     "circkit_normalize": (_sz, [_vp, _sz, _vp, ctypes.POINTER(_i)]),
@@ -254,3 +262,33 @@ def canonicalize(s):
 
 def xxh3_64(s):
     return default_context().xxh3_64(s)
+
+
+def fasta_parse(text, first_chunk=True, final_chunk=True):
+    """FASTA text -> (records, normalized_bytes, offsets, consumed); records = [(head, raw_seq)] with seq_io
+    semantics.  Host logic (circkit_fasta_parse); raises ValueError on a format error."""
+    lib = load_library()
+    text = bytes(text)
+    buf = ctypes.create_string_buffer(text, max(len(text), 1))
+    h = _vp()
+    consumed = _sz(0)
+    rc = lib.circkit_fasta_parse(ctypes.addressof(buf), len(text), int(first_chunk), int(final_chunk), ctypes.byref(h),
+                                 ctypes.byref(consumed))
+    try:
+        if rc != OK:
+            raise ValueError(lib.circkit_fasta_error(h).decode() if h else "fasta parse failed")
+        n = lib.circkit_fasta_n_records(h)
+        offs = np.ctypeslib.as_array(ctypes.cast(lib.circkit_fasta_offsets(h), ctypes.POINTER(ctypes.c_uint64)),
+                                     shape=(n + 1,)).copy()
+        total = int(offs[-1])
+        data = np.ctypeslib.as_array(ctypes.cast(lib.circkit_fasta_bytes(h), ctypes.POINTER(ctypes.c_uint8)),
+                                     shape=(max(total, 1),)).copy()[:total]
+        recs = []
+        ho, hl, ro, rl = _sz(0), _sz(0), _sz(0), _sz(0)
+        for i in range(n):
+            lib.circkit_fasta_record(h, i, ctypes.byref(ho), ctypes.byref(hl), ctypes.byref(ro), ctypes.byref(rl))
+            recs.append((text[ho.value:ho.value + hl.value], text[ro.value:ro.value + rl.value]))
+        return recs, data, offs, consumed.value
+    finally:
+        if h:
+            lib.circkit_fasta_free(h)

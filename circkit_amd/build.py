@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcirckit_hip.so")
 CLI = os.path.join(HERE, "circkit")
-HIP_SOURCES = ["circkit_hip.hip"]
-HOST_SOURCES = ["fasta_host.cpp", "circkit_cli.cpp"]
+HIP_SOURCES = ["circkit_hip.hip", "fasta_host.cpp"]
+HOST_SOURCES = ["circkit_cli.cpp"]
 
 
 def _hipcc():
@@ -51,7 +51,7 @@ def build_cli(force=False):
     if not force and not _stale(CLI, _all_deps() + [LIB]):
         return CLI
     cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-o", CLI] + srcs + \
-          ["-L" + HERE, "-lcirckit_hip", "-Wl,-rpath,$ORIGIN"]
+          ["-L" + HERE, "-lcirckit_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
     subprocess.check_call(cmd)
     return CLI
 

@@ -1,0 +1,267 @@
+// circkit_cli.cpp -- `circkit canonicalize` / `circkit uniq` on the MI355X path.
+//
+// Host-side mirror of the reference's two subcommand drivers (same flags, defaults, output format, exit
+// behaviour):
+//   src/commands.rs:112-149   Canonicalize{input,output,threads}, Uniq{input,output,canonicalize,table,threads}
+//   src/canonicalize.rs:7-51  reader -> worker(normalize + canonicalize) -> writer(">head\nSEQ\n")
+//   src/uniq.rs:15-88         same worker; xxh3 -> first-seen map; kept record or (id, duplicate_id) table row
+//   src/utils.rs:9-84         input (file | stdin, compression sniffed by magic bytes), output (compression by
+//                             extension), table writer (tab for .tsv, comma otherwise)
+// The per-record work runs on the GPU through the C ABI (include/circkit.h); this file only streams text in,
+// packs CSR batches (fasta_host.h) and writes text out.  There is no CPU compute path: without a usable GPU the
+// program fails like any other I/O error.  Compressed streams are piped through the system's gzip / bzip2 / xz /
+// zstd binaries.
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/circkit.h"
+#include "fasta_host.h"
+
+namespace {
+
+struct Options {
+    std::string cmd, input, output, table;
+    bool has_input = false, has_output = false, has_table = false, canonicalize = false;
+    int threads = 0, device = 0;
+};
+
+[[noreturn]] void die(const std::string& msg)
+{
+    fprintf(stderr, "Error: %s\n", msg.c_str());     // anyhow's `Error: ...` on stderr, exit code 1 (src/main.rs:13,39)
+    exit(1);
+}
+
+void usage(FILE* f)
+{
+    fprintf(f,
+            "circkit (MI355X build)\n\nUSAGE:\n"
+            "    circkit canonicalize [INPUT] [-o <OUTPUT>] [-t <THREADS>]\n"
+            "    circkit uniq [INPUT] [-o <OUTPUT>] [-c|--canonicalize] [--table <TABLE>] [-t <THREADS>]\n\n"
+            "    INPUT   FASTA file, may be gzip, bzip, xz, or zstd compressed [default: stdin]\n"
+            "    -o      output FASTA path; .gz/.bz2/.xz/.zst compress [default: stdout]\n"
+            "    -c      uniq: output canonicalized sequences (aliases --norm --canon)\n"
+            "    --table uniq: CSV (TSV for .tsv) of id,duplicate_id\n"
+            "    -t      host threads (accepted for compatibility; records are batched to the GPU)\n"
+            "    --device <N>  GPU index [default: 0]\n");
+}
+
+Options parse_args(int argc, char** argv)
+{
+    Options o;
+    if (argc < 2) { usage(stderr); exit(2); }
+    o.cmd = argv[1];
+    if (o.cmd == "-h" || o.cmd == "--help" || o.cmd == "help") { usage(stdout); exit(0); }
+    if (o.cmd != "canonicalize" && o.cmd != "uniq") {
+        fprintf(stderr, "error: unrecognized subcommand '%s' (this build provides canonicalize and uniq)\n", o.cmd.c_str());
+        exit(2);
+    }
+    for (int i = 2; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto value = [&](const char* name) -> std::string {
+            if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", name); exit(2); }
+            return argv[++i];
+        };
+        if (a == "-o" || a == "--output") { o.output = value("--output"); o.has_output = true; }
+        else if (a.rfind("--output=", 0) == 0) { o.output = a.substr(9); o.has_output = true; }
+        else if (a == "-t" || a == "--threads") o.threads = atoi(value("--threads").c_str());
+        else if (a.rfind("--threads=", 0) == 0) o.threads = atoi(a.c_str() + 10);
+        else if (a == "--device") o.device = atoi(value("--device").c_str());
+        else if (o.cmd == "uniq" && (a == "-c" || a == "--canonicalize" || a == "--norm" || a == "--canon")) o.canonicalize = true;
+        else if (o.cmd == "uniq" && a == "--table") { o.table = value("--table"); o.has_table = true; }
+        else if (o.cmd == "uniq" && a.rfind("--table=", 0) == 0) { o.table = a.substr(8); o.has_table = true; }
+        else if (a == "-h" || a == "--help") { usage(stdout); exit(0); }
+        else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); exit(2); }
+        else if (!o.has_input) { o.input = a; o.has_input = true; }
+        else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); exit(2); }
+    }
+    return o;
+}
+
+std::string shell_quote(const std::string& s)
+{
+    std::string q = "'";
+    for (char c : s) { if (c == '\'') q += "'\\''"; else q += c; }
+    return q + "'";
+}
+
+// src/utils.rs:9-27: open file or stdin, sniff the compression format by magic bytes (niffler)
+struct Input {
+    FILE* f = nullptr;
+    bool piped = false;
+};
+
+const char* sniff(const uint8_t* m, size_t n)
+{
+    if (n >= 2 && m[0] == 0x1f && m[1] == 0x8b) return "gzip";
+    if (n >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') return "bzip2";
+    if (n >= 6 && m[0] == 0xfd && m[1] == '7' && m[2] == 'z' && m[3] == 'X' && m[4] == 'Z' && m[5] == 0) return "xz";
+    if (n >= 4 && m[0] == 0x28 && m[1] == 0xb5 && m[2] == 0x2f && m[3] == 0xfd) return "zstd";
+    return nullptr;
+}
+
+Input open_input(const Options& o)
+{
+    Input in;
+    if (!o.has_input) {
+        if (isatty(0)) die("No stdin detected. Did you mean to include a file argument?");     // src/utils.rs:18-20
+        in.f = stdin;
+        return in;
+    }
+    FILE* f = fopen(o.input.c_str(), "rb");
+    if (!f) die(std::string(strerror(errno)) + " (os error " + std::to_string(errno) + ")");  // tests/canon_uniq.rs:9-16
+    uint8_t magic[6];
+    const size_t got = fread(magic, 1, sizeof magic, f);
+    const char* tool = sniff(magic, got);
+    if (!tool) { rewind(f); in.f = f; return in; }
+    fclose(f);
+    const std::string cmd = std::string(tool) + " -dc " + shell_quote(o.input);
+    in.f = popen(cmd.c_str(), "r");
+    if (!in.f) die(std::string("could not run ") + tool + " to decompress the input");
+    in.piped = true;
+    return in;
+}
+
+// src/utils.rs:29-72: compression by extension with the reference's levels (gz 6, bz2 9, xz 6, zst 1)
+struct Output {
+    FILE* f = nullptr;
+    bool piped = false;
+    std::vector<char> buf;
+};
+
+Output open_output(const Options& o)
+{
+    Output out;
+    out.buf.resize(8 << 20);
+    if (!o.has_output) { out.f = stdout; setvbuf(stdout, out.buf.data(), _IOFBF, out.buf.size()); return out; }
+    const std::string& p = o.output;
+    auto ends = [&](const char* e) { const size_t n = strlen(e); return p.size() >= n && p.compare(p.size() - n, n, e) == 0; };
+    const char* tool = ends(".gz") ? "gzip -6" : ends(".bz2") ? "bzip2 -9" : ends(".xz") ? "xz -6" : ends(".zst") ? "zstd -1 -q" : nullptr;
+    FILE* probe = fopen(p.c_str(), "wb");
+    if (!probe) die("Could not create output file " + p + ". Are you sure it's not actually a directory?");   // src/utils.rs:46-49
+    if (!tool) { out.f = probe; setvbuf(out.f, out.buf.data(), _IOFBF, out.buf.size()); return out; }
+    fclose(probe);
+    const std::string cmd = std::string(tool) + " -c > " + shell_quote(p);
+    out.f = popen(cmd.c_str(), "w");
+    if (!out.f) die(std::string("could not run `") + tool + "` to compress the output");
+    out.piped = true;
+    return out;
+}
+
+void close_output(Output& out)
+{
+    if (!out.f) return;
+    if (fflush(out.f) != 0) die("failed to write output");
+    if (out.piped) { if (pclose(out.f) != 0) die("the output compressor failed (is it installed?)"); }
+    else if (out.f != stdout) fclose(out.f);
+    out.f = nullptr;
+}
+
+void check(circkit_ctx* ctx, int rc)
+{
+    if (rc != CIRCKIT_OK) die(std::string("GPU path failed: ") + circkit_last_error(ctx));
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    const Options opt = parse_args(argc, argv);
+    Input in = open_input(opt);
+    Output out = open_output(opt);
+    FILE* table = nullptr;
+    char delim = ',';
+    if (opt.has_table) {
+        table = fopen(opt.table.c_str(), "wb");
+        if (!table) die("Could not create output table.");                                 // src/utils.rs:83
+        if (opt.table.size() >= 4 && opt.table.compare(opt.table.size() - 4, 4, ".tsv") == 0) delim = '\t';   // src/utils.rs:77-80
+    }
+    circkit_ctx* ctx = nullptr;
+    const int rc = circkit_ctx_create(opt.device, &ctx);
+    if (rc != CIRCKIT_OK) die(std::string("no usable MI355X GPU (device ") + std::to_string(opt.device) + "): " +
+                               (ctx ? circkit_last_error(ctx) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
+
+    const bool uniq = opt.cmd == "uniq";
+    const size_t CHUNK = 256u << 20;                  // text per GPU batch
+    std::vector<uint8_t> text;
+    size_t have = 0;
+    bool eof = false, first = true, table_header = false;
+    ckhost::Batch b;
+    std::vector<uint8_t> canon;
+    std::vector<uint64_t> hash, first_seen;
+    std::vector<std::string> ids;                     // uniq: id of every kept record, by global index
+    std::vector<uint64_t> kept_slot;                  // global index -> slot in ids (or ~0)
+    uint64_t base = 0;
+    std::string err, line;
+
+    while (!eof || have) {
+        // fill the chunk; grow it when a single record does not fit
+        if (text.size() < have + CHUNK) text.resize(have + CHUNK);
+        while (!eof && have < text.size()) {
+            const size_t got = fread(text.data() + have, 1, text.size() - have, in.f);
+            if (got == 0) { if (ferror(in.f)) die("failed to read the input"); eof = true; }
+            have += got;
+        }
+        size_t consumed = 0;
+        if (!ckhost::parse_chunk(text.data(), have, first, eof, b, &consumed, err)) die(err);
+        if (consumed == 0 && !eof) { text.resize(text.size() * 2); continue; }   // one record longer than the chunk
+        first = false;
+        const uint64_t n = b.n();
+        if (n) {
+            const uint64_t total = b.offsets[n];
+            const bool want_bytes = !uniq || opt.canonicalize;
+            canon.resize(total + 64);
+            if (uniq) hash.resize(n);
+            check(ctx, circkit_canonicalize_batch(ctx, b.bytes.data(), b.offsets.data(), n, want_bytes ? canon.data() : nullptr,
+                                                  nullptr, nullptr, uniq ? hash.data() : nullptr));
+            if (uniq) {
+                first_seen.resize(n);
+                check(ctx, circkit_uniq_first_seen(ctx, hash.data(), n, base, first_seen.data()));
+                if (table) kept_slot.resize(base + n, ~0ull);
+            }
+            for (uint64_t i = 0; i < n; ++i) {
+                const ckhost::Span h = b.head[i];
+                bool keep = true;
+                if (uniq) {
+                    keep = first_seen[i] == base + i;
+                    const ckhost::Span id = ckhost::record_id(text.data(), h);
+                    if (keep) {
+                        if (table) { kept_slot[base + i] = ids.size(); ids.emplace_back((const char*)text.data() + id.off, id.len); }
+                    } else if (table) {                                        // src/uniq.rs:63-70
+                        line.clear();
+                        if (!table_header) { line += "id"; line += delim; line += "duplicate_id\n"; table_header = true; }
+                        const std::string& fid = ids[kept_slot[first_seen[i]]];
+                        ckhost::csv_field(line, (const uint8_t*)fid.data(), fid.size(), delim);
+                        line += delim;
+                        ckhost::csv_field(line, text.data() + id.off, id.len, delim);
+                        line += '\n';
+                        fwrite(line.data(), 1, line.size(), table);
+                    }
+                }
+                if (!keep) continue;
+                fputc('>', out.f);                                             // src/canonicalize.rs:33-37, src/uniq.rs:50-61
+                fwrite(text.data() + h.off, 1, h.len, out.f);
+                fputc('\n', out.f);
+                if (want_bytes) fwrite(canon.data() + b.offsets[i], 1, b.offsets[i + 1] - b.offsets[i], out.f);
+                else fwrite(text.data() + b.raw[i].off, 1, b.raw[i].len, out.f);
+                fputc('\n', out.f);
+            }
+            if (ferror(out.f)) die("failed to write output");
+            base += n;
+        }
+        memmove(text.data(), text.data() + consumed, have - consumed);
+        have -= consumed;
+        if (eof && consumed == 0 && have) die("FASTA parse error: trailing bytes could not be parsed");
+    }
+    close_output(out);
+    if (table) fclose(table);
+    if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
+    else if (in.f != stdin) fclose(in.f);
+    circkit_ctx_destroy(ctx);
+    return 0;
+}

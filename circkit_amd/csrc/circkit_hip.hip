@@ -143,6 +143,24 @@ __global__ void uniq_lookup_kernel(const uint64_t* hash, uint64_t n, const unsig
     }
 }
 
+// moves every (key, smallest index) entry of an old table into a bigger one
+__global__ void uniq_rehash_kernel(const unsigned long long* okeys, const unsigned long long* ovals, uint64_t oslots,
+                                   unsigned long long* keys, unsigned long long* vals, uint64_t mask)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < oslots; i += stride) {
+        const uint64_t h = okeys[i], v = ovals[i];
+        if (i + 1 == oslots) { if (v != UNIQ_EMPTY) atomicMin(&vals[mask + 1], (unsigned long long)v); continue; }   // the EMPTY-key slot
+        if (h == UNIQ_EMPTY) continue;
+        uint64_t s = uniq_slot(h, mask);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
+            if (old == UNIQ_EMPTY || old == h) { atomicMin(&vals[s], (unsigned long long)v); break; }
+            s = (s + 1) & mask;
+        }
+    }
+}
+
 __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long long v)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -181,7 +199,7 @@ struct circkit_ctx {
     uint8_t* d_scratch = nullptr; uint64_t cap_scratch = 0;   // canonical bytes of hash-only batches
     // uniq table
     unsigned long long *d_keys = nullptr, *d_vals = nullptr;
-    uint64_t uniq_mask = 0;
+    uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
 };
 
 namespace {
@@ -537,6 +555,47 @@ int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
     hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_vals, cap + 1, (unsigned long long)UNIQ_EMPTY);
     CK_HIP(c, hipMemsetAsync(c->d_counters + 4, 0, 4, c->stream));
     CK_HIP(c, hipGetLastError());
+    c->uniq_count = 0;
+    return CIRCKIT_OK;
+}
+
+// Host-buffer form for streaming hosts (the CLI): folds this batch's hashes into the table, growing (and
+// rehashing) it as the stream gets longer, and returns the winners.  Synchronizes.
+int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, uint64_t base_index, uint64_t* first_seen)
+{
+    if (!c || (n && (!hash || !first_seen))) return CIRCKIT_ERR_INVALID_ARG;
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    if (!c->d_keys || (c->uniq_count + n) * 2 > c->uniq_mask + 1) {
+        uint64_t cap = 1 << 16;
+        while (cap < 4 * (c->uniq_count + n)) cap <<= 1;
+        unsigned long long *nk = nullptr, *nv = nullptr;
+        CK_HIP(c, hipMalloc(&nk, (cap + 1) * 8));
+        CK_HIP(c, hipMalloc(&nv, (cap + 1) * 8));
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nk, cap + 1, (unsigned long long)UNIQ_EMPTY);
+        hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nv, cap + 1, (unsigned long long)UNIQ_EMPTY);
+        if (c->d_keys) {
+            hipLaunchKernelGGL(uniq_rehash_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_keys, c->d_vals,
+                               c->uniq_mask + 2, nk, nv, cap - 1);
+            CK_HIP(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(c->d_keys); (void)hipFree(c->d_vals);
+        } else {
+            CK_HIP(c, hipMemsetAsync(c->d_counters + 4, 0, 4, c->stream));
+        }
+        c->d_keys = nk; c->d_vals = nv; c->uniq_mask = cap - 1;
+    }
+    int rc = ensure_staging(c, 0, n);
+    if (rc) return rc;
+    CK_HIP(c, hipMemcpyAsync(c->d_hash, hash, n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_hash, n, base_index, c->d_keys,
+                       c->d_vals, c->uniq_mask, c->d_counters + 4);
+    uint64_t* d_fs = (uint64_t*)c->d_off;          // staging reuse: offsets buffer holds >= n + 1 u64
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_hash, n, c->d_keys, c->d_vals,
+                       c->uniq_mask, d_fs);
+    CK_HIP(c, hipGetLastError());
+    CK_HIP(c, hipMemcpyAsync(first_seen, d_fs, n * 8, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    c->uniq_count += n;
     return CIRCKIT_OK;
 }
 
@@ -549,6 +608,7 @@ int circkit_uniq_insert_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
     hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, base_index, c->d_keys,
                        c->d_vals, c->uniq_mask, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
+    c->uniq_count += n;
     return CIRCKIT_OK;
 }
 

@@ -1,0 +1,150 @@
+// fasta_host.cpp -- see fasta_host.h.  Host logic only.
+#include "fasta_host.h"
+
+#include <string.h>
+
+#include "../../include/circkit.h"
+
+namespace ckhost {
+
+const uint8_t* normalize_lut()
+{
+    static uint8_t lut[256];
+    static bool ready = false;
+    if (!ready) {
+        // needletail 0.5.1 sequence::normalize(_, iupac = false): ACGTN- kept, acg -> upper, t/u/U -> T,
+        // . ~ -> -, whitespace dropped, everything else -> N
+        for (int v = 0; v < 256; ++v) lut[v] = 'N';
+        const char* keep = "ACGTN-";
+        for (int i = 0; keep[i]; ++i) lut[(uint8_t)keep[i]] = (uint8_t)keep[i];
+        lut['a'] = 'A'; lut['c'] = 'C'; lut['g'] = 'G'; lut['t'] = 'T'; lut['u'] = 'T'; lut['U'] = 'T';
+        lut['.'] = '-'; lut['~'] = '-';
+        lut[' '] = 0; lut['\t'] = 0; lut['\r'] = 0; lut['\n'] = 0;
+        ready = true;
+    }
+    return lut;
+}
+
+bool parse_chunk(const uint8_t* text, size_t n, bool first_chunk, bool final_chunk, Batch& out, size_t* consumed,
+                 std::string& err)
+{
+    out.clear();
+    out.text = text;
+    size_t pos = 0;
+    if (first_chunk) {
+        while (pos < n && (text[pos] == '\n' || text[pos] == '\r')) ++pos;      // leading blank lines
+        if (pos < n && text[pos] != '>') {
+            err = "FASTA parse error: expected '>' at the start of the first record";
+            return false;
+        }
+    }
+    // where may we stop?  A record is complete once the start of the next one ("\n>") has been seen.
+    size_t limit = n;
+    if (!final_chunk) {
+        size_t k = n;
+        limit = pos;
+        while (k > pos + 1) {
+            const void* p = memrchr(text + pos, '>', k - pos);
+            if (!p) break;
+            const size_t g = (const uint8_t*)p - text;
+            if (g > pos && text[g - 1] == '\n') { limit = g; break; }
+            k = g;
+        }
+    }
+    const uint8_t* lut = normalize_lut();
+    out.offsets.push_back(0);
+    while (pos < limit) {
+        // header line
+        const uint8_t* eol = (const uint8_t*)memchr(text + pos, '\n', limit - pos);
+        size_t hend = eol ? (size_t)(eol - text) : limit;
+        size_t hlen = hend - (pos + 1);
+        if (hlen && text[pos + 1 + hlen - 1] == '\r') --hlen;
+        out.head.push_back(Span{ pos + 1, hlen });
+        size_t s0 = eol ? hend + 1 : limit;
+        // sequence: up to the next "\n>" (or the chunk limit)
+        size_t s1 = limit, next = limit;
+        for (size_t k = s0; k < limit;) {
+            const uint8_t* g = (const uint8_t*)memchr(text + k, '>', limit - k);
+            if (!g) break;
+            const size_t gi = g - text;
+            if (gi == s0 || text[gi - 1] == '\n') { s1 = gi; next = gi; break; }
+            k = gi + 1;
+        }
+        size_t rlen = s1 - s0;
+        if (rlen && text[s0 + rlen - 1] == '\n') --rlen;       // final line terminator is not part of seq()
+        if (rlen && text[s0 + rlen - 1] == '\r') --rlen;
+        out.raw.push_back(Span{ s0, rlen });
+        // normalize while packing
+        const size_t base = out.bytes.size();
+        out.bytes.resize(base + rlen);
+        uint8_t* dst = out.bytes.data() + base;
+        size_t m = 0;
+        for (size_t k = 0; k < rlen; ++k) {
+            const uint8_t o = lut[text[s0 + k]];
+            dst[m] = o;
+            m += (o != 0);
+        }
+        out.bytes.resize(base + m);
+        out.offsets.push_back(out.bytes.size());
+        pos = next;
+    }
+    out.bytes.resize(out.bytes.size() + 64, 0);
+    if (consumed) *consumed = limit;
+    return true;
+}
+
+void csv_field(std::string& out, const uint8_t* p, size_t n, char delim)
+{
+    bool quote = n == 0;
+    for (size_t i = 0; i < n && !quote; ++i) quote = p[i] == (uint8_t)delim || p[i] == '"' || p[i] == '\n' || p[i] == '\r';
+    if (!quote) { out.append((const char*)p, n); return; }
+    out.push_back('"');
+    for (size_t i = 0; i < n; ++i) {
+        if (p[i] == '"') out.push_back('"');
+        out.push_back((char)p[i]);
+    }
+    out.push_back('"');
+}
+
+}  // namespace ckhost
+
+// ------------------------------------------------------------------------------------------------
+// C ABI of the packer (include/circkit.h): lets a host in another language -- and the CPU-only tests --
+// drive the FASTA -> CSR step without touching C++ types.
+// ------------------------------------------------------------------------------------------------
+struct circkit_fasta_batch {
+    ckhost::Batch b;
+    std::string err;
+};
+
+extern "C" {
+
+int circkit_fasta_parse(const uint8_t* text, size_t n, int first_chunk, int final_chunk, circkit_fasta_batch** out,
+                        size_t* consumed)
+{
+    if (!out || (n && !text)) return CIRCKIT_ERR_INVALID_ARG;
+    circkit_fasta_batch* fb = new circkit_fasta_batch();
+    *out = fb;
+    if (!ckhost::parse_chunk(text, n, first_chunk != 0, final_chunk != 0, fb->b, consumed, fb->err)) return CIRCKIT_ERR_INVALID_ARG;
+    return CIRCKIT_OK;
+}
+
+const char* circkit_fasta_error(const circkit_fasta_batch* fb) { return fb ? fb->err.c_str() : "null batch"; }
+uint64_t circkit_fasta_n_records(const circkit_fasta_batch* fb) { return fb ? fb->b.n() : 0; }
+const uint8_t* circkit_fasta_bytes(const circkit_fasta_batch* fb) { return fb ? fb->b.bytes.data() : nullptr; }
+const uint64_t* circkit_fasta_offsets(const circkit_fasta_batch* fb) { return fb ? fb->b.offsets.data() : nullptr; }
+
+int circkit_fasta_record(const circkit_fasta_batch* fb, uint64_t i, size_t* head_off, size_t* head_len, size_t* raw_off,
+                         size_t* raw_len)
+{
+    if (!fb || i >= fb->b.n()) return CIRCKIT_ERR_INVALID_ARG;
+    if (head_off) *head_off = fb->b.head[i].off;
+    if (head_len) *head_len = fb->b.head[i].len;
+    if (raw_off) *raw_off = fb->b.raw[i].off;
+    if (raw_len) *raw_len = fb->b.raw[i].len;
+    return CIRCKIT_OK;
+}
+
+void circkit_fasta_free(circkit_fasta_batch* fb) { delete fb; }
+
+}  // extern "C"

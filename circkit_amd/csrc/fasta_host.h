@@ -1,0 +1,49 @@
+// fasta_host.h -- host side of the canonicalize / uniq path: FASTA record parsing with seq_io semantics and
+// the CSR batch packer that feeds the GPU.  Replaces, on the host:
+//   seq_io 0.3.2 fasta::Reader + parallel_fasta record hand-off   (call sites src/canonicalize.rs:14-20, src/uniq.rs:24-32)
+//   needletail 0.5.1 sequence::normalize(seq, false) in the worker closure (src/canonicalize.rs:24-27, src/uniq.rs:35-38)
+// Everything here is plain C++ host logic (no GPU); the compute it feeds is the C ABI of include/circkit.h.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace ckhost {
+
+struct Span { size_t off, len; };
+
+// One parsed chunk of FASTA text: per record the header span, the raw sequence span (interior line breaks kept,
+// final line break dropped -- what seq_io's RefRecord::seq() returns) and the normalized bytes in CSR layout.
+struct Batch {
+    const uint8_t* text = nullptr;          // the chunk the spans point into (owned by the caller)
+    std::vector<Span> head, raw;
+    std::vector<uint8_t> bytes;             // normalized payload, + 64 bytes of zero padding
+    std::vector<uint64_t> offsets;          // n_records + 1
+    size_t n() const { return head.size(); }
+    void clear() { head.clear(); raw.clear(); bytes.clear(); offsets.clear(); }
+};
+
+// needletail normalize LUT: 0 = drop (space, \t, \r, \n), otherwise the output byte.
+const uint8_t* normalize_lut();
+
+// Parses every complete record in text[0, n).  If `final_chunk` is false the last record may be cut by the chunk
+// end, so parsing stops before the last record start and *consumed tells the caller where to resume; with
+// `final_chunk` everything is consumed.  `first_chunk` enables the leading-blank-line skip and the
+// "must start with '>'" check.  Returns false and sets err on a format error.
+bool parse_chunk(const uint8_t* text, size_t n, bool first_chunk, bool final_chunk, Batch& out, size_t* consumed,
+                 std::string& err);
+
+// seq_io Record::id(): header up to the first space.
+inline Span record_id(const uint8_t* text, Span head)
+{
+    size_t k = 0;
+    while (k < head.len && text[head.off + k] != ' ') ++k;
+    return Span{ head.off, k };
+}
+
+// csv crate field quoting (QuoteStyle::Necessary): quote when the field holds the delimiter, a quote, CR or LF
+// (or is empty); quotes are doubled.
+void csv_field(std::string& out, const uint8_t* p, size_t n, char delim);
+
+}  // namespace ckhost

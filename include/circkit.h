@@ -117,6 +117,30 @@ int circkit_uniq_reset(circkit_ctx* ctx, uint64_t expected_keys);
 int circkit_uniq_insert_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t base_index);
 int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen);
 
+/* Host-buffer form for streaming hosts (the CLI's batch loop): folds this batch's hashes (global indices
+ * base_index .. base_index + n - 1) into the ctx table -- created and grown on demand, earlier batches kept --
+ * and returns first_seen[i] for the batch.  Synchronizes. */
+int circkit_uniq_first_seen(circkit_ctx* ctx, const uint64_t* hash, uint64_t n, uint64_t base_index,
+                            uint64_t* first_seen);
+
+/* ---- FASTA -> CSR packer (host logic, no GPU) --------------------------------------------------- */
+/* Replaces seq_io 0.3.2's fasta::Reader record boundaries + the normalize step of the worker closure
+ * (src/canonicalize.rs:14-27, src/uniq.rs:24-38).  Parses the complete records of text[0, n): header span,
+ * raw sequence span (RefRecord::seq(): interior line breaks kept, final one dropped) and the normalized
+ * bytes in CSR layout (padded with 64 zero bytes).  first_chunk: skip leading blank lines and require '>';
+ * final_chunk = 0: the last record may be cut by the chunk end, parsing stops at its start and *consumed
+ * says where to resume.  Returns CIRCKIT_ERR_INVALID_ARG on a format error (message: circkit_fasta_error). */
+typedef struct circkit_fasta_batch circkit_fasta_batch;
+int circkit_fasta_parse(const uint8_t* text, size_t n, int first_chunk, int final_chunk, circkit_fasta_batch** out,
+                        size_t* consumed);
+const char* circkit_fasta_error(const circkit_fasta_batch* b);
+uint64_t circkit_fasta_n_records(const circkit_fasta_batch* b);
+const uint8_t* circkit_fasta_bytes(const circkit_fasta_batch* b);
+const uint64_t* circkit_fasta_offsets(const circkit_fasta_batch* b);
+int circkit_fasta_record(const circkit_fasta_batch* b, uint64_t i, size_t* head_off, size_t* head_len, size_t* raw_off,
+                         size_t* raw_len);
+void circkit_fasta_free(circkit_fasta_batch* b);
+
 /* ---- synthetic input on the device (bench / tests) ------------------------------ */
 /* Fills d_bytes[0..n_bases) with uniform ACGT from the counter-based generator keyed by
  * (seed, first_base + i) -- the same bytes oracle/ck_oracle_synth_fill produces on the host. */

@@ -1,0 +1,140 @@
+"""GPU: the `circkit` binary (C++ host + C ABI + HIP kernels) against the reference's CLI tests
+(tests/canon_uniq.rs, tests/compression.rs) and its fixture files."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "ref_examples")
+BIN = os.path.join(ROOT, "circkit_amd", "circkit")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+    g.build()
+    assert os.path.exists(BIN)
+
+
+def run(*args, stdin=None):
+    return subprocess.run([BIN] + list(args), input=stdin, capture_output=True, timeout=120)
+
+
+def id_seq_map(data):
+    """tests/common.rs:33-88 (bio::io::fasta): id -> sequence with line breaks removed."""
+    from oracle import oracle as O
+    return {O.record_id(h): s.replace(b"\n", b"").replace(b"\r", b"") for h, s in O.read_fasta(data)}
+
+
+def fixture(d, name):
+    return os.path.join(GOLDEN, d, name)
+
+
+def test_file_doesnt_exist():
+    r = run("canonicalize", "test/file/doesnt/exist")          # tests/canon_uniq.rs:8-17
+    assert r.returncode != 0
+    assert b"No such file or directory" in r.stderr
+
+
+def test_simple_fasta_file_to_stdout(tmp_path):
+    f = tmp_path / "simple.fasta"                               # tests/canon_uniq.rs:19-31
+    f.write_bytes(b">seq1\nATGCA")
+    r = run("canonicalize", str(f))
+    assert r.returncode == 0 and b">seq1\nAATGC" in r.stdout
+
+
+def test_stdin_to_stdout():
+    r = run("canonicalize", stdin=b">a desc\nTT\nATG\n>b\nAATGGA")
+    assert r.returncode == 0 and r.stdout == b">a desc\nAACAT\n>b\nAAATGG\n" and r.stderr == b""
+
+
+@pytest.mark.parametrize("command,directory", [
+    ("canonicalize", "simple"), ("uniq", "simple"),
+    ("canonicalize", "multiple_sequences"), ("uniq", "multiple_sequences"),
+    ("canonicalize", "multiple_sequences_split_lines"), ("uniq", "multiple_sequences_split_lines"),
+    ("canonicalize", "rna_input"), ("uniq", "rna_input"),
+    ("uniq", "repeated")])
+@pytest.mark.parametrize("threads", ["1", "4"])
+def test_fasta_files(command, directory, threads, tmp_path):
+    out = tmp_path / "out.fasta"                                # tests/canon_uniq.rs:33-89
+    args = [command, fixture(directory, "in.fasta"), "--threads", threads, "-o", str(out)]
+    if command == "uniq":
+        args.append("--canonicalize")
+    r = run(*args)
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b""
+    assert id_seq_map(out.read_bytes()) == id_seq_map(open(fixture(directory, "out.fasta"), "rb").read())
+
+
+@pytest.mark.parametrize("command", ["canonicalize", "uniq"])
+@pytest.mark.parametrize("ext,tool", [("gz", "gzip"), ("bz2", "bzip2"), ("xz", "xz"), ("zst", "zstd")])
+def test_compressed_output(command, ext, tool, tmp_path):
+    if not shutil.which(tool):                                  # tests/compression.rs:8-69
+        pytest.skip("%s is not installed on this box" % tool)
+    out = tmp_path / ("out.fasta." + ext)
+    args = [command, fixture("compressed_output", "in.fasta"), "-o", str(out)] + (["--canonicalize"] if command == "uniq" else [])
+    r = run(*args)
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b""
+    subprocess.check_call([tool, "-d", str(out)])
+    assert id_seq_map((tmp_path / "out.fasta").read_bytes()) == id_seq_map(open(fixture("compressed_output", "out.fasta"), "rb").read())
+
+
+@pytest.mark.parametrize("command", ["canonicalize", "uniq"])
+@pytest.mark.parametrize("ext,tool", [("gz", "gzip"), ("bz2", "bzip2"), ("xz", "xz"), ("zst", "zstd")])
+def test_compressed_input(command, ext, tool, tmp_path):
+    if not shutil.which(tool):                                  # tests/compression.rs:71-119
+        pytest.skip("%s is not installed on this box" % tool)
+    out = tmp_path / "out.fasta"
+    args = [command, fixture("compressed_input", "in.fasta." + ext), "-o", str(out)] + (["--canonicalize"] if command == "uniq" else [])
+    r = run(*args)
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b""
+    assert id_seq_map(out.read_bytes()) == id_seq_map(open(fixture("compressed_input", "out.fasta"), "rb").read())
+
+
+def test_uniq_table_and_raw_output(tmp_path):
+    """src/uniq.rs:50-70: without --canonicalize the kept record prints its RAW bytes; duplicates become table rows."""
+    from oracle import oracle as O
+    data = open(fixture("repeated", "in.fasta"), "rb").read()
+    for ext, delim in (("csv", b","), ("tsv", b"\t")):
+        out, table = tmp_path / ("o." + ext + ".fasta"), tmp_path / ("t." + ext)
+        r = run("uniq", fixture("repeated", "in.fasta"), "-o", str(out), "--table", str(table))
+        assert r.returncode == 0 and r.stderr == b""
+        exp_fa, exp_table = O.cli_uniq(data, canonical_out=False, delimiter=delim)
+        assert out.read_bytes() == exp_fa
+        assert table.read_bytes() == exp_table
+    # no duplicates -> empty table file (src/commands.rs:142)
+    out, table = tmp_path / "o2.fasta", tmp_path / "t2.csv"
+    r = run("uniq", fixture("multiple_sequences", "in.fasta"), "-o", str(out), "--table", str(table))
+    assert r.returncode == 0 and table.read_bytes() == b""
+
+
+def test_whole_file_outputs_match_the_record_loop_restatement(tmp_path):
+    """Byte-for-byte output files on a realistic input (676 records) for canonicalize and both uniq modes."""
+    from oracle import oracle as O
+    src = os.path.join(GOLDEN, "nim_cated", "realistic_input.fasta")
+    data = open(src, "rb").read()
+    out = tmp_path / "c.fasta"
+    assert run("canonicalize", src, "-o", str(out)).returncode == 0
+    assert out.read_bytes() == O.cli_canonicalize(data)
+    # duplicate the file onto itself with rotated copies so uniq has work to do
+    recs = O.read_fasta(data)
+    twice = data + b"".join(b">dup_" + h + b"\n" + s[7:] + s[:7] + b"\n" for h, s in recs[:200])
+    f2 = tmp_path / "twice.fasta"
+    f2.write_bytes(twice)
+    for canon in (True, False):
+        o, t = tmp_path / "u.fasta", tmp_path / "u.csv"
+        args = ["uniq", str(f2), "-o", str(o), "--table", str(t)] + (["-c"] if canon else [])
+        assert run(*args).returncode == 0
+        exp_fa, exp_t = O.cli_uniq(twice, canonical_out=canon)
+        assert o.read_bytes() == exp_fa
+        assert t.read_bytes() == exp_t
+
+
+def test_not_fasta_is_an_error(tmp_path):
+    f = tmp_path / "x.txt"
+    f.write_bytes(b"ACGT\n")
+    r = run("canonicalize", str(f))
+    assert r.returncode != 0 and b"Error" in r.stderr
