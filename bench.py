@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="records timed on the host cores (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
+                    help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
+                         "strand duplicates, hash + first-seen); mixed = configs[3] (1M records, L ~ 1/L on [200, 20000])")
     args = ap.parse_args()
 
     import numpy as np
@@ -70,17 +73,60 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     N, L = args.records, args.length
-    total = N * L
+    if args.workload == "mixed":
+        # config 4: lengths with P(L) ~ 1/L on [200, 20000] (log-uniform), seed 45
+        N = min(N, 1_000_000)
+        g = torch.Generator(device="cpu").manual_seed(45 + rank)
+        u = torch.rand(N, generator=g, dtype=torch.float64)
+        lens = torch.exp(np.log(200.0) + u * (np.log(20000.0) - np.log(200.0))).to(torch.int64)
+        offs = torch.zeros(N + 1, dtype=torch.int64)
+        offs[1:] = torch.cumsum(lens, 0)
+        total = int(offs[-1])
+        d_off = offs.to(dev)
+    else:
+        total = N * L
+        d_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        ctx.fixed_offsets_device(0, L, N, d_off)
     d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
     d_out = torch.empty(total + 64, dtype=torch.uint8, device=dev)
-    d_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
     # global base index keeps every rank's shard distinct: record g of the job = bases [g*L, (g+1)*L)
-    ctx.synth_fill_device(42, rank * total, total, d_bytes)
-    ctx.fixed_offsets_device(0, L, N, d_off)
+    ctx.synth_fill_device(42 if args.workload != "mixed" else 45, rank * total, total, d_bytes)
+    d_hash = d_fs = None
+    if args.workload == "uniq":
+        # config 3: the second half of the shard = uniformly chosen records of the first half, rotated by a
+        # uniform k and reverse-complemented with p = 0.5; then the whole shard is shuffled (seeds 43/44)
+        half = N // 2
+        gen = torch.Generator(device=dev).manual_seed(43 + rank)
+        lut = torch.arange(256, dtype=torch.uint8, device=dev)
+        for a_, b_ in zip(b"ACGT", b"TGCA"):
+            lut[a_] = b_
+        view = d_bytes[:N * L].view(N, L)
+        col = torch.arange(L, device=dev)
+        for s0 in range(half, N, 500_000):
+            m = min(500_000, N - s0)
+            src = torch.randint(0, half, (m,), generator=gen, device=dev)
+            k = torch.randint(0, L, (m, 1), generator=gen, device=dev)
+            rows = torch.gather(view[src], 1, (col.unsqueeze(0) + k) % L)
+            flip = torch.rand(m, generator=gen, device=dev) < 0.5
+            rows[flip] = lut[rows[flip].flip(1).long()]
+            view[s0:s0 + m] = rows
+        perm = torch.randperm(N, generator=torch.Generator(device=dev).manual_seed(44 + rank), device=dev)
+        for c0 in range(0, L, 100):                       # shuffle records column block by column block (bounded temp)
+            view[:, c0:c0 + 100] = view[perm, c0:c0 + 100]
+        d_hash = torch.empty(N, dtype=torch.int64, device=dev)
+        d_fs = torch.empty(N, dtype=torch.int64, device=dev)
+        del view, perm
     torch.cuda.synchronize()
 
     def step():
-        ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out)
+        if args.workload == "uniq":
+            # canonical bytes + XXH3 + first-seen table: what `circkit uniq --canonicalize` computes per batch
+            ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out, out_xxh3=d_hash)
+            ctx.uniq_reset(N)
+            ctx.uniq_insert_device(d_hash, N, rank * N)
+            ctx.uniq_lookup_device(d_hash, N, d_fs)
+        else:
+            ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out)
 
     for _ in range(args.warmup):
         step()
@@ -112,25 +158,36 @@ def main():
     if rank == 0:
         seq_per_s = world * N * args.steps / dt
         algo_bytes = 2 * total + 8 * N                 # read L + write L per record + one u64 offset
+        if args.workload == "uniq":
+            algo_bytes += 8 * N + 32 * N               # + u64 hash per record + table insert/lookup (key + value each)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         result = {
-            "metric": "canonicalize sequences/sec (10M x 1kb synthetic FASTA payload)",
+            "metric": {"canonicalize": "canonicalize sequences/sec (10M x 1kb synthetic FASTA payload)",
+                       "uniq": "uniq sequences/sec (10M x 1kb, ~50% rotational/strand duplicates)",
+                       "mixed": "canonicalize sequences/sec (1M records, 200b-20kb log-uniform lengths)"}[args.workload],
             "value": seq_per_s,
             "unit": "sequences/s",
-            "gbases_per_s": seq_per_s * L / 1e9,
+            "gbases_per_s": world * total * args.steps / dt / 1e9,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "canonicalize, %d records x %d b per GPU, uniform ACGT seed 42, device-resident CSR "
-                                   "(BASELINE configs[1])" % (N, L),
+            "config": {"workload": {"canonicalize": "canonicalize, %d records x %d b per GPU, uniform ACGT seed 42, "
+                                                    "device-resident CSR (BASELINE configs[1])" % (N, L),
+                                    "uniq": "uniq --canonicalize, %d records x %d b per GPU, half are rotated / reverse-"
+                                            "complemented copies, shuffled (BASELINE configs[2])" % (N, L),
+                                    "mixed": "canonicalize, %d records, lengths log-uniform on [200, 20000], %d bases per "
+                                             "GPU (BASELINE configs[3])" % (N, total)}[args.workload],
                        "records_per_gpu": N, "record_len": L,
                        "parallelism": "records sharded over %d GPU(s), no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(N, L),
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic(N, L) if args.workload == "canonicalize" else None,
                          "kernel": "canon_fast_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
         }
-        if world == 1 and not args.no_cpu:
+        if args.workload == "uniq":
+            result["unique_records"] = int((d_fs == torch.arange(rank * N, rank * N + N, device=dev)).sum().item())
+        if world == 1 and not args.no_cpu and args.workload == "canonicalize":
             from oracle import oracle as O
             S = min(args.cpu_sample, N)
             h_in = d_bytes[:S * L].cpu().numpy()

@@ -168,8 +168,8 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint32_t rec, 
 }
 
 // Software-pipelined grid-stride loop of one wave over a ring of NB 1 KiB LDS buffers: while record k is
-// computed, the bytes of records k + stride .. k + (NB-1)*stride are in flight (LDS-DMA) and so are the
-// offsets of record k + NB*stride (scalar load, lgkmcnt).  Memory-level parallelism is what the copy
+// computed, the bytes of records k + stride .. k + (NB-1)*stride are in flight (LDS-DMA); offsets come by
+// scalar load (lgkmcnt, so they never touch the vmcnt bookkeeping).  Memory-level parallelism is what the copy
 // microbenchmark (tools/microbench/copy_bench.hip) shows this chip needs: one 1 KiB request per wave tops
 // out near 4.2 TB/s, several in flight reach 5.4+.
 // vmcnt bookkeeping: every step issues exactly one DMA (depth D = NB-1 ahead).  When record k+1's bytes
@@ -181,17 +181,16 @@ struct FastSlot { uint64_t off; uint32_t n; };
 
 template <int NB>
 CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uint32_t last, uint32_t stride,
-                      const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill, uint32_t* fill_buf, ck_u32x4v& sq)
+                      const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill, uint32_t* fill_buf)
 {
     constexpr int D = NB - 1;
-    // the offsets of record min(rec + D*stride, last) were requested one step ago: DMA it into the free buffer
+    // offsets of record min(rec + D*stride, last) by scalar load, then its bytes by DMA into the free buffer
+    const uint32_t rn = rec + D * stride;
     uint64_t o0, o1;
-    sload_wait(sq, o0, o1);
+    sload_u64x2(a.offsets + (rn < last ? rn : last), o0, o1);
     fill.off = o0;
     fill.n = (uint32_t)(o1 - o0);
     fast_issue(a, o0, fill.n, fill_buf);
-    const uint32_t rn = rec + NB * stride;
-    sq = sload_u64x2(a.offsets + (rn < last ? rn : last));
     if (!(fast_eligible(cur.n) && fast_process(a, lut, rec, cur.off, cur.n, fast_fetch(cur_buf))) && lane_id() == 0)
         a.defer_list[atomic_add_u32(a.defer_count, 1u)] = rec;
     if (a.out_bytes) vmem_wait<2 * D - 1>(); else vmem_wait<D - 1>();
@@ -214,14 +213,12 @@ CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32
         fast_issue(a, p0, s[i].n, lds + 256 * i);
     }
     vmem_wait<NB - 2>();
-    const uint32_t rp = rec + (NB - 1) * stride;
-    ck_u32x4v sq = sload_u64x2(a.offsets + (rp < last ? rp : last));
     for (;;) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             constexpr int dummy = 0; (void)dummy;
             const int f = (i + NB - 1) % NB;
-            fast_step<NB>(a, lut, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f, sq);
+            fast_step<NB>(a, lut, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f);
             rec += stride;
             if (rec >= total) return;
         }

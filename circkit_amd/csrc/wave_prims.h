@@ -155,9 +155,11 @@ CK_DEV uint32_t load4(const uint8_t* p)
 CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 
 // Two consecutive u64 (a CSR offset pair) through the scalar cache: s_load_dwordx4, tracked by lgkmcnt, so
-// it never forces a vmcnt(0) that would drain the prefetched record bytes.  p must be wave-uniform and the
-// memory read-only for the kernel's lifetime.  The load is asynchronous: call sload_wait() before use.
-typedef uint32_t ck_u32x4v __attribute__((ext_vector_type(4)));
+// it never forces a vmcnt(0) that would drain the prefetched record bytes.  The wait is INSIDE the same asm
+// statement: an asynchronous form (load now, wait a step later) is unsafe -- between the two statements the
+// compiler considers the destination SGPRs ordinary values and may copy or reuse them while the load is
+// still in flight (seen in the ISA: the registers were recycled for loop arithmetic; rare garbage offsets).
+// p must be wave-uniform and the memory read-only for the kernel's lifetime.
 // LDS-DMA: every lane copies 16 bytes from its own global address straight into LDS at
 // lds_dst + 16*lane (global_load_lds_dwordx4; M0 carries the wave-uniform LDS base).  No VGPR destination,
 // so the compiler cannot touch the data before it lands; completion is OUR bookkeeping: vmem_wait<N>(),
@@ -176,15 +178,11 @@ CK_DEV void vmem_wait()
 {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
-CK_DEV ck_u32x4v sload_u64x2(const uint64_t* p)
+typedef uint32_t ck_u32x4v __attribute__((ext_vector_type(4)));
+CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b)
 {
     ck_u32x4v r;
-    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=s"(r) : "s"(p) : "memory");
-    return r;
-}
-CK_DEV void sload_wait(ck_u32x4v& r, uint64_t& a, uint64_t& b)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r) :: "memory");
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
     a = ((uint64_t)r.y << 32) | r.x;
     b = ((uint64_t)r.w << 32) | r.z;
 }
@@ -289,15 +287,7 @@ struct ck_u32x4v { uint32_t x, y, z, w; };
 CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), gsrc, 16); }
 template <int N>
 CK_DEV void vmem_wait() {}
-CK_DEV ck_u32x4v sload_u64x2(const uint64_t* p)
-{
-    ck_u32x4v r; memcpy(&r, p, 16); return r;
-}
-CK_DEV void sload_wait(ck_u32x4v& r, uint64_t& a, uint64_t& b)
-{
-    a = ((uint64_t)r.y << 32) | r.x;
-    b = ((uint64_t)r.w << 32) | r.z;
-}
+CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b) { a = p[0]; b = p[1]; }
 
 }  // namespace ck
 #endif
