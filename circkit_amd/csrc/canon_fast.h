@@ -180,8 +180,9 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint32_t rec, 
 struct FastSlot { uint64_t off; uint32_t n; };
 
 template <int NB>
-CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uint32_t last, uint32_t stride,
-                      const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill, uint32_t* fill_buf)
+CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t* blk_count, uint32_t block, uint32_t rec,
+                      uint32_t last, uint32_t stride, const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill,
+                      uint32_t* fill_buf)
 {
     constexpr int D = NB - 1;
     // offsets of record min(rec + D*stride, last) by scalar load, then its bytes by DMA into the free buffer
@@ -191,13 +192,14 @@ CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uin
     fill.off = o0;
     fill.n = (uint32_t)(o1 - o0);
     fast_issue(a, o0, fill.n, fill_buf);
-    if (!(fast_eligible(cur.n) && fast_process(a, lut, rec, cur.off, cur.n, fast_fetch(cur_buf))) && lane_id() == 0)
-        a.defer_list[atomic_add_u32(a.defer_count, 1u)] = rec;
+    if (!(fast_eligible(cur.n) && fast_process(a, lut, rec, cur.off, cur.n, fast_fetch(cur_buf))))
+        defer_record(a, blk_count, block, rec);
     if (a.out_bytes) vmem_wait<2 * D - 1>(); else vmem_wait<D - 1>();
 }
 
 template <int NB>
-CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* lds, uint32_t wave_id, uint32_t n_waves)
+CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* lds, uint32_t* blk_count, uint32_t block,
+                                 uint32_t wave_id, uint32_t n_waves)
 {
     // record indices fit 32 bits (n_records < 2^31 is an ABI precondition); prefetches past the end re-fetch
     // the last record (harmless, keeps one DMA per step)
@@ -218,7 +220,7 @@ CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32
         for (int i = 0; i < NB; ++i) {
             constexpr int dummy = 0; (void)dummy;
             const int f = (i + NB - 1) % NB;
-            fast_step<NB>(a, lut, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f);
+            fast_step<NB>(a, lut, blk_count, block, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f);
             rec += stride;
             if (rec >= total) return;
         }

@@ -27,28 +27,37 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-// One wavefront per record, WPB wavefronts per workgroup, each with its own LDS slice.  The waves of
-// a workgroup take consecutive records, so a workgroup streams one contiguous span of the CSR payload.
+// One wavefront per record, WPB wavefronts per workgroup, each with its own LDS slice; the last LDS dword is the
+// workgroup's deferral counter.  Consumes the segmented list of the previous stage (or all records).
 template <int WPB>
 __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* blk_count = lds + WPB * a.slice_dw;
+    if (threadIdx.x == 0) *blk_count = 0;
+    __syncthreads();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
-    const uint32_t wave = ck::uniform(blockIdx.x * WPB + wib);
-    ck::canon_wave_loop(a, lds + wib * a.slice_dw, wave, gridDim.x * WPB);
+    ck::canon_wave_loop(a, lds + wib * a.slice_dw, blk_count, blockIdx.x, gridDim.x, wib, WPB);
+    __syncthreads();
+    if (threadIdx.x == 0 && a.defer_count) a.defer_count[blockIdx.x] = *blk_count;
 }
 
 // The streaming kernel (canon_fast.h): packed words in registers, a ring of FAST_NB 1 KiB LDS buffers per wave
-// for the record prefetch, plus the 1 KiB decode table per workgroup.
+// for the record prefetch, the 1 KiB decode table and the deferral counter per workgroup.
 constexpr int FAST_NB = CK_FAST_NB;
 __global__ __launch_bounds__(256, CK_FAST_WPE) void canon_fast_kernel(ck::CanonArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 256 * FAST_NB + 256];
-    ck::fast_lut_init(lds + 4 * 256 * FAST_NB, threadIdx.x, 256);
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 256 * FAST_NB + 256 + 4];
+    uint32_t* lut = lds + 4 * 256 * FAST_NB;
+    uint32_t* blk_count = lut + 256;
+    ck::fast_lut_init(lut, threadIdx.x, 256);
+    if (threadIdx.x == 0) *blk_count = 0;
     __syncthreads();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + wib);
-    ck::canon_fast_wave_loop<FAST_NB>(a, lds + 4 * 256 * FAST_NB, lds + wib * 256 * FAST_NB, wave, gridDim.x * 4);
+    ck::canon_fast_wave_loop<FAST_NB>(a, lut, lds + wib * 256 * FAST_NB, blk_count, blockIdx.x, wave, gridDim.x * 4);
+    __syncthreads();
+    if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
 }
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).
@@ -171,7 +180,7 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 // LDS tiers (dwords per wave).  A: 4 waves x 4 KiB per workgroup, 8 workgroups per CU.
 // B: one wave with 40 KiB (4 per CU).  C: one wave with the whole 160 KiB CU.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t TIER_A_DW = 1024, TIER_B_DW = 10240, TIER_C_DW = 40704;
+constexpr uint32_t TIER_A_DW = 1024, TIER_B_DW = 10240, TIER_C_DW = 40700;   // + 4 dwords per workgroup for the deferral counter
 constexpr int N_CU = 256;
 
 }  // namespace
@@ -187,11 +196,13 @@ struct circkit_ctx {
     uint32_t debug_flags = 0;            // CIRCKIT_DEBUG_FLAGS: timing ablations of the streaming kernel (bits 8..)
     std::string err;
     uint8_t* d_comp = nullptr;
-    uint32_t* d_counters = nullptr;      // [0..2] deferred counts of fast kernel, tiers A,B; [3] unprocessed; [4] uniq overflow
-    uint32_t* d_list_f = nullptr;        // deferred lists: fast kernel -> tier A -> tier B -> tier C
+    uint32_t* d_counters = nullptr;      // [3] unprocessed records; [4] uniq table overflow
+    // segmented deferral lists: streaming kernel -> tier A -> tier B -> tier C (one segment per producing workgroup)
+    uint32_t* d_list_f = nullptr;
     uint32_t* d_list_a = nullptr;
     uint32_t* d_list_b = nullptr;
-    uint64_t list_cap = 0;
+    uint32_t* d_seg_counts = nullptr;    // [3 * seg_alloc]
+    uint64_t list_cap = 0, seg_alloc = 0;
     // host-batch staging (grow only)
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_strand = nullptr;
     uint64_t* d_off = nullptr; uint32_t* d_idx = nullptr; uint64_t* d_hash = nullptr;
@@ -220,17 +231,24 @@ int fail(circkit_ctx* c, int code, const char* fmt, ...)
                         "%s failed: %s", #call, hipGetErrorString(e_));                             \
     } while (0)
 
-int ensure_lists(circkit_ctx* c, uint64_t n)
+int ensure_lists(circkit_ctx* c, uint64_t entries, uint64_t segs)
 {
-    if (n <= c->list_cap) return CIRCKIT_OK;
-    if (c->d_list_f) { (void)hipFree(c->d_list_f); c->d_list_f = nullptr; }
-    if (c->d_list_a) { (void)hipFree(c->d_list_a); c->d_list_a = nullptr; }
-    if (c->d_list_b) { (void)hipFree(c->d_list_b); c->d_list_b = nullptr; }
-    c->list_cap = 0;
-    CK_HIP(c, hipMalloc(&c->d_list_f, n * sizeof(uint32_t)));
-    CK_HIP(c, hipMalloc(&c->d_list_a, n * sizeof(uint32_t)));
-    CK_HIP(c, hipMalloc(&c->d_list_b, n * sizeof(uint32_t)));
-    c->list_cap = n;
+    if (entries > c->list_cap) {
+        if (c->d_list_f) { (void)hipFree(c->d_list_f); c->d_list_f = nullptr; }
+        if (c->d_list_a) { (void)hipFree(c->d_list_a); c->d_list_a = nullptr; }
+        if (c->d_list_b) { (void)hipFree(c->d_list_b); c->d_list_b = nullptr; }
+        c->list_cap = 0;
+        CK_HIP(c, hipMalloc(&c->d_list_f, entries * sizeof(uint32_t)));
+        CK_HIP(c, hipMalloc(&c->d_list_a, entries * sizeof(uint32_t)));
+        CK_HIP(c, hipMalloc(&c->d_list_b, entries * sizeof(uint32_t)));
+        c->list_cap = entries;
+    }
+    if (segs > c->seg_alloc) {
+        if (c->d_seg_counts) { (void)hipFree(c->d_seg_counts); c->d_seg_counts = nullptr; }
+        c->seg_alloc = 0;
+        CK_HIP(c, hipMalloc(&c->d_seg_counts, 3 * segs * sizeof(uint32_t)));
+        c->seg_alloc = segs;
+    }
     return CIRCKIT_OK;
 }
 
@@ -240,13 +258,18 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
-    int rc = ensure_lists(c, n);
+    // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs
+    // to workgroup b); tier B takes 4 segments per workgroup, tier C is the end of the line
+    const uint64_t blocks = (n + 3) / 4;
+    const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
+    const uint32_t cap = (uint32_t)(4 * ((n + 4ull * G - 1) / (4ull * G)));       // records one workgroup can see
+    const unsigned GB = (G + 3) / 4;
+    int rc = ensure_lists(c, (uint64_t)G * cap + 4ull * cap, G);
     if (rc) return rc;
     if (d_hash && !d_out) {
         // hash-only (uniq without --canonicalize): the canonical bytes go to a ctx-owned scratch the hash kernel
-        // reads back.  Its size is offsets[n] - offsets[0], fetched from the device (one small synchronous copy).
-        uint64_t first = 0, lastoff = 0;
-        CK_HIP(c, hipMemcpyAsync(&first, d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
+        // reads back.  Its size is offsets[n], fetched from the device (one small synchronous copy).
+        uint64_t lastoff = 0;
         CK_HIP(c, hipMemcpyAsync(&lastoff, d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
         CK_HIP(c, hipStreamSynchronize(c->stream));
         if (lastoff + 64 > c->cap_scratch) {
@@ -255,34 +278,37 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             c->cap_scratch = lastoff + 64;
         }
         d_out = c->d_scratch;       // indexed by the same absolute offsets as the input
-        (void)first;
     }
     CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
+    uint32_t* cnt_f = c->d_seg_counts;
+    uint32_t* cnt_a = cnt_f + c->seg_alloc;
+    uint32_t* cnt_b = cnt_a + c->seg_alloc;
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr;
     a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags | c->debug_flags;
-    const uint64_t blocks = (n + 3) / 4;
-    const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
-    a.list = nullptr; a.list_count = nullptr; a.defer_list = c->d_list_f; a.defer_count = c->d_counters + 0;
+    a.list = nullptr; a.list_count = nullptr;
+    a.defer_list = c->d_list_f; a.defer_count = cnt_f; a.out_seg_cap = cap;
     a.slice_dw = 0;
-    {
-        const unsigned fgrid = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
-        hipLaunchKernelGGL(canon_fast_kernel, dim3(fgrid), dim3(256), 0, c->stream, a);
-    }
-    a.list = c->d_list_f; a.list_count = c->d_counters + 0; a.defer_list = c->d_list_a; a.defer_count = c->d_counters + 1;
+    hipLaunchKernelGGL(canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
+    a.list = c->d_list_f; a.list_count = cnt_f; a.in_nseg = G; a.in_seg_cap = cap; a.segs_per_block = 1;
+    a.defer_list = c->d_list_a; a.defer_count = cnt_a; a.out_seg_cap = cap;
     a.slice_dw = TIER_A_DW;
-    hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), 4 * TIER_A_DW * 4, c->stream, a);
-    a.list = c->d_list_a; a.list_count = c->d_counters + 1; a.defer_list = c->d_list_b; a.defer_count = c->d_counters + 2;
+    hipLaunchKernelGGL(canon_kernel<4>, dim3(G), dim3(256), (4 * TIER_A_DW + 4) * 4, c->stream, a);
+    a.list = c->d_list_a; a.list_count = cnt_a; a.in_nseg = G; a.in_seg_cap = cap; a.segs_per_block = 4;
+    a.defer_list = c->d_list_b; a.defer_count = cnt_b; a.out_seg_cap = 4 * cap;
     a.slice_dw = TIER_B_DW;
-    hipLaunchKernelGGL(canon_kernel<1>, dim3(N_CU * 4), dim3(64), TIER_B_DW * 4, c->stream, a);
-    a.list = c->d_list_b; a.list_count = c->d_counters + 2; a.defer_list = nullptr; a.defer_count = nullptr;
+    hipLaunchKernelGGL(canon_kernel<1>, dim3(GB), dim3(64), (TIER_B_DW + 4) * 4, c->stream, a);
+    a.list = c->d_list_b; a.list_count = cnt_b; a.in_nseg = GB; a.in_seg_cap = 4 * cap;
+    a.segs_per_block = (GB + N_CU - 1) / N_CU;
+    a.defer_list = nullptr; a.defer_count = nullptr; a.out_seg_cap = 0;
     a.slice_dw = TIER_C_DW;
-    hipLaunchKernelGGL(canon_kernel<1>, dim3(N_CU), dim3(64), TIER_C_DW * 4, c->stream, a);
+    hipLaunchKernelGGL(canon_kernel<1>, dim3((GB + a.segs_per_block - 1) / a.segs_per_block), dim3(64), (TIER_C_DW + 4) * 4,
+                       c->stream, a);
     if (d_hash) {
-        hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash);
+        hipLaunchKernelGGL(xxh3_kernel, dim3(G), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash);
     }
     CK_HIP(c, hipEventRecord(c->ev1, c->stream));
     CK_HIP(c, hipGetLastError());
@@ -385,7 +411,7 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = (uint8_t)y[i]; comp[(uint8_t)x[i] + 32] = (uint8_t)(y[i] + 32); }
     CK_HIP(c, hipMemcpy(c->d_comp, comp, 256, hipMemcpyHostToDevice));
     CK_HIP(c, hipFuncSetAttribute((const void*)canon_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)(TIER_C_DW * 4)));
+                                  (int)((TIER_C_DW + 4) * 4)));
     return CIRCKIT_OK;
 }
 
@@ -394,7 +420,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     if (!c) return CIRCKIT_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* ptrs[] = { c->d_comp, c->d_counters, c->d_list_f, c->d_list_a, c->d_list_b, c->d_in, c->d_out, c->d_strand, c->d_off,
+    void* ptrs[] = { c->d_comp, c->d_counters, c->d_seg_counts, c->d_list_f, c->d_list_a, c->d_list_b, c->d_in, c->d_out, c->d_strand, c->d_off,
                      c->d_idx, c->d_hash, c->d_keys, c->d_vals, c->d_scratch };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

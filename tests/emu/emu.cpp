@@ -94,19 +94,21 @@ void run_wave(void (*body)(void*), void* arg)
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t wave_id, n_waves; };
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t* blk_count; uint32_t block, nblocks, wib; };
 void wave_body(void* p)
 {
     Launch* L = (Launch*)p;
-    ck::canon_wave_loop(L->a, L->lds, L->wave_id, L->n_waves);
+    ck::canon_wave_loop(L->a, L->lds, L->blk_count, L->block, L->nblocks, L->wib, 4);
 }
 void fast_body(void* p)
 {
     Launch* L = (Launch*)p;
-    ck::canon_fast_wave_loop<4>(L->a, L->lut, L->lds, L->wave_id, L->n_waves);
+    ck::canon_fast_wave_loop<4>(L->a, L->lut, L->lds, L->blk_count, L->block, L->block * 4 + L->wib, L->nblocks * 4);
 }
 }
 
+// Same launch sequence as the host library: streaming kernel over everything (workgroups of 4 waves, each with
+// its own deferral segment), then one LDS tier over the segmented list.  n_waves is rounded up to whole workgroups.
 extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                       uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
                                       uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
@@ -116,29 +118,36 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
     const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
-    // same launch sequence as the host library: streaming kernel over everything, then the LDS tier
-    std::vector<uint32_t> lds((slice_dw > 1024 ? slice_dw : 1024) + 16), list_f(n_records + 1), deferred(n_records + 1);
-    uint32_t count_f = 0, defer_count = 0, status = 0;
-    Launch L;
-    L.a = ck::CanonArgs{ bytes, offsets, n_records, out_bytes, out_index, out_strand, out_hash,
-                         nullptr, nullptr, list_f.data(), &count_f, &status, comp, 0, flags };
-    L.lds = lds.data();
-    uint32_t lut[256];
+    const uint32_t G = (n_waves + 3) / 4;
+    const uint32_t cap = (uint32_t)(4 * ((n_records + 4ull * G - 1) / (4ull * G))) + 4;
+    std::vector<uint32_t> lds((slice_dw > 1024 ? slice_dw : 1024) + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
+    uint32_t status = 0, lut[256];
     ck::fast_lut_init(lut, 0, 1);
-    L.lut = lut;
-    L.n_waves = n_waves;
-    for (uint32_t w = 0; w < n_waves; ++w) {
-        L.wave_id = w;
-        ck::emu::run_wave(fast_body, &L);
+    Launch L;
+    L.a = ck::CanonArgs{};
+    L.a.bytes = bytes; L.a.offsets = offsets; L.a.n_records = n_records;
+    L.a.out_bytes = out_bytes; L.a.out_index = out_index; L.a.out_strand = out_strand; L.a.out_hash = out_hash;
+    L.a.status = &status; L.a.comp_lut = comp; L.a.flags = flags;
+    L.a.defer_list = list_f.data(); L.a.defer_count = cnt_f.data(); L.a.out_seg_cap = cap;
+    L.lds = lds.data(); L.lut = lut; L.nblocks = G;
+    uint32_t total_f = 0, total_a = 0;
+    for (uint32_t b = 0; b < G; ++b) {
+        uint32_t blk = 0;
+        L.block = b; L.blk_count = &blk;
+        for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(fast_body, &L); }
+        cnt_f[b] = blk; total_f += blk;
     }
-    if (n_fast) *n_fast = (uint32_t)n_records - count_f;
-    L.a.list = list_f.data(); L.a.list_count = &count_f;
-    L.a.defer_list = deferred.data(); L.a.defer_count = &defer_count; L.a.slice_dw = slice_dw;
-    for (uint32_t w = 0; w < n_waves; ++w) {
-        L.wave_id = w;
-        ck::emu::run_wave(wave_body, &L);
+    if (n_fast) *n_fast = (uint32_t)n_records - total_f;
+    L.a.list = list_f.data(); L.a.list_count = cnt_f.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1;
+    L.a.defer_list = list_a.data(); L.a.defer_count = cnt_a.data(); L.a.out_seg_cap = cap; L.a.slice_dw = slice_dw;
+    for (uint32_t b = 0; b < G; ++b) {
+        uint32_t blk = 0;
+        L.block = b; L.blk_count = &blk;
+        for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(wave_body, &L); }
+        cnt_a[b] = blk; total_a += blk;
     }
-    if (n_deferred) *n_deferred = defer_count;
+    if (n_deferred) *n_deferred = total_a;
     return (int)status;
 }
 
