@@ -180,7 +180,7 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 // LDS tiers (dwords per wave).  A: 4 waves x 4 KiB per workgroup, 8 workgroups per CU.
 // B: one wave with 40 KiB (4 per CU).  C: one wave with the whole 160 KiB CU.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t TIER_A_DW = 1024, TIER_B_DW = 10240, TIER_C_DW = 40700;   // + 4 dwords per workgroup for the deferral counter
+constexpr uint32_t TIER_A_DW = 1023, TIER_B_DW = 10236, TIER_C_DW = 40700;   // + 4 dwords per workgroup for the deferral counter: 16 KiB, 40 KiB, 159 KiB
 constexpr int N_CU = 256;
 
 }  // namespace
