@@ -63,9 +63,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CIRCKIT_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import circkit_amd
     ctx = circkit_amd.Context(local_rank)
@@ -131,7 +133,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -141,7 +143,7 @@ def main():
         step()
     ev1.record(stream)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -149,7 +151,7 @@ def main():
     unprocessed = ctx.batch_status()
     if unprocessed:
         raise SystemExit("%d records were not processed" % unprocessed)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,7 +211,7 @@ def main():
                 print(json.dumps(result))
                 raise SystemExit("GPU output differs from the CPU oracle on the sample")
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 
