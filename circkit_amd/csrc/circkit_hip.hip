@@ -180,7 +180,14 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 // LDS tiers (dwords per wave).  A: 4 waves x 4 KiB per workgroup, 8 workgroups per CU.
 // B: one wave with 40 KiB (4 per CU).  C: one wave with the whole 160 KiB CU.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t TIER_A_DW = 1023, TIER_B_DW = 10236, TIER_C_DW = 40700;   // + 4 dwords per workgroup for the deferral counter: 16 KiB, 40 KiB, 159 KiB
+// LDS tiers of the general kernel (dwords per wave; + 4 dwords per workgroup for the deferral counter).
+//   A: 4 waves x 4 KiB per workgroup (10 workgroups per CU)   2-bit records up to ~6.5 kb
+//   B: 1 wave x 14 KiB (11 per CU)                            2-bit up to ~22 kb: covers BASELINE config 4's 20 kb tail
+//   C: 1 wave x 40 KiB (4 per CU)                             2-bit up to ~65 kb, byte-mode up to ~19 kb
+//   D: 1 wave x 159 KiB (the whole CU)                        2-bit up to ~260 kb, byte-mode up to ~76 kb
+constexpr int N_TIERS = 4;
+constexpr uint32_t TIER_DW[N_TIERS] = { 1023, 3580, 10236, 40700 };
+constexpr uint32_t TIER_D_DW = TIER_DW[3];
 constexpr int N_CU = 256;
 
 }  // namespace
@@ -198,10 +205,8 @@ struct circkit_ctx {
     uint8_t* d_comp = nullptr;
     uint32_t* d_counters = nullptr;      // [3] unprocessed records; [4] uniq table overflow
     // segmented deferral lists: streaming kernel -> tier A -> tier B -> tier C (one segment per producing workgroup)
-    uint32_t* d_list_f = nullptr;
-    uint32_t* d_list_a = nullptr;
-    uint32_t* d_list_b = nullptr;
-    uint32_t* d_seg_counts = nullptr;    // [3 * seg_alloc]
+    uint32_t* d_lists[N_TIERS] = { nullptr, nullptr, nullptr, nullptr };   // input list of tier i (output of the stage before)
+    uint32_t* d_seg_counts = nullptr;    // [N_TIERS * seg_alloc]
     uint64_t list_cap = 0, seg_alloc = 0;
     // host-batch staging (grow only)
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_strand = nullptr;
@@ -234,19 +239,17 @@ int fail(circkit_ctx* c, int code, const char* fmt, ...)
 int ensure_lists(circkit_ctx* c, uint64_t entries, uint64_t segs)
 {
     if (entries > c->list_cap) {
-        if (c->d_list_f) { (void)hipFree(c->d_list_f); c->d_list_f = nullptr; }
-        if (c->d_list_a) { (void)hipFree(c->d_list_a); c->d_list_a = nullptr; }
-        if (c->d_list_b) { (void)hipFree(c->d_list_b); c->d_list_b = nullptr; }
         c->list_cap = 0;
-        CK_HIP(c, hipMalloc(&c->d_list_f, entries * sizeof(uint32_t)));
-        CK_HIP(c, hipMalloc(&c->d_list_a, entries * sizeof(uint32_t)));
-        CK_HIP(c, hipMalloc(&c->d_list_b, entries * sizeof(uint32_t)));
+        for (int i = 0; i < N_TIERS; ++i) {
+            if (c->d_lists[i]) { (void)hipFree(c->d_lists[i]); c->d_lists[i] = nullptr; }
+            CK_HIP(c, hipMalloc(&c->d_lists[i], entries * sizeof(uint32_t)));
+        }
         c->list_cap = entries;
     }
     if (segs > c->seg_alloc) {
         if (c->d_seg_counts) { (void)hipFree(c->d_seg_counts); c->d_seg_counts = nullptr; }
         c->seg_alloc = 0;
-        CK_HIP(c, hipMalloc(&c->d_seg_counts, 3 * segs * sizeof(uint32_t)));
+        CK_HIP(c, hipMalloc(&c->d_seg_counts, N_TIERS * segs * sizeof(uint32_t)));
         c->seg_alloc = segs;
     }
     return CIRCKIT_OK;
@@ -258,13 +261,12 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
-    // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs
-    // to workgroup b); tier B takes 4 segments per workgroup, tier C is the end of the line
+    // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs to
+    // workgroup b); the one-wave tiers B, C take 4 segments per workgroup each; tier D is the end of the line
     const uint64_t blocks = (n + 3) / 4;
     const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
     const uint32_t cap = (uint32_t)(4 * ((n + 4ull * G - 1) / (4ull * G)));       // records one workgroup can see
-    const unsigned GB = (G + 3) / 4;
-    int rc = ensure_lists(c, (uint64_t)G * cap + 4ull * cap, G);
+    int rc = ensure_lists(c, (uint64_t)G * cap + 64ull * cap, G);
     if (rc) return rc;
     if (d_hash && !d_out) {
         // hash-only (uniq without --canonicalize): the canonical bytes go to a ctx-owned scratch the hash kernel
@@ -281,32 +283,32 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     }
     CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
-    uint32_t* cnt_f = c->d_seg_counts;
-    uint32_t* cnt_a = cnt_f + c->seg_alloc;
-    uint32_t* cnt_b = cnt_a + c->seg_alloc;
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr;
     a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags | c->debug_flags;
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
     a.list = nullptr; a.list_count = nullptr;
-    a.defer_list = c->d_list_f; a.defer_count = cnt_f; a.out_seg_cap = cap;
+    a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
     hipLaunchKernelGGL(canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
-    a.list = c->d_list_f; a.list_count = cnt_f; a.in_nseg = G; a.in_seg_cap = cap; a.segs_per_block = 1;
-    a.defer_list = c->d_list_a; a.defer_count = cnt_a; a.out_seg_cap = cap;
-    a.slice_dw = TIER_A_DW;
-    hipLaunchKernelGGL(canon_kernel<4>, dim3(G), dim3(256), (4 * TIER_A_DW + 4) * 4, c->stream, a);
-    a.list = c->d_list_a; a.list_count = cnt_a; a.in_nseg = G; a.in_seg_cap = cap; a.segs_per_block = 4;
-    a.defer_list = c->d_list_b; a.defer_count = cnt_b; a.out_seg_cap = 4 * cap;
-    a.slice_dw = TIER_B_DW;
-    hipLaunchKernelGGL(canon_kernel<1>, dim3(GB), dim3(64), (TIER_B_DW + 4) * 4, c->stream, a);
-    a.list = c->d_list_b; a.list_count = cnt_b; a.in_nseg = GB; a.in_seg_cap = 4 * cap;
-    a.segs_per_block = (GB + N_CU - 1) / N_CU;
-    a.defer_list = nullptr; a.defer_count = nullptr; a.out_seg_cap = 0;
-    a.slice_dw = TIER_C_DW;
-    hipLaunchKernelGGL(canon_kernel<1>, dim3((GB + a.segs_per_block - 1) / a.segs_per_block), dim3(64), (TIER_C_DW + 4) * 4,
-                       c->stream, a);
+    unsigned nseg = G;              // segments / capacity of the list the next tier consumes
+    uint32_t seg_cap = cap;
+    for (int t = 0; t < N_TIERS; ++t) {
+        const bool last = t == N_TIERS - 1;
+        const unsigned spb = t == 0 ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
+        const unsigned grid = (nseg + spb - 1) / spb;
+        a.list = c->d_lists[t]; a.list_count = c->d_seg_counts + (uint64_t)t * c->seg_alloc;
+        a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb;
+        a.defer_list = last ? nullptr : c->d_lists[t + 1];
+        a.defer_count = last ? nullptr : c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
+        a.out_seg_cap = spb * seg_cap;
+        a.slice_dw = TIER_DW[t];
+        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), (4 * TIER_DW[t] + 4) * 4, c->stream, a);
+        else hipLaunchKernelGGL(canon_kernel<1>, dim3(grid), dim3(64), (TIER_DW[t] + 4) * 4, c->stream, a);
+        nseg = grid;
+        seg_cap = spb * seg_cap;
+    }
     if (d_hash) {
         hipLaunchKernelGGL(xxh3_kernel, dim3(G), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash);
     }
@@ -411,7 +413,7 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = (uint8_t)y[i]; comp[(uint8_t)x[i] + 32] = (uint8_t)(y[i] + 32); }
     CK_HIP(c, hipMemcpy(c->d_comp, comp, 256, hipMemcpyHostToDevice));
     CK_HIP(c, hipFuncSetAttribute((const void*)canon_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((TIER_C_DW + 4) * 4)));
+                                  (int)((TIER_D_DW + 4) * 4)));
     return CIRCKIT_OK;
 }
 
@@ -420,7 +422,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     if (!c) return CIRCKIT_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* ptrs[] = { c->d_comp, c->d_counters, c->d_seg_counts, c->d_list_f, c->d_list_a, c->d_list_b, c->d_in, c->d_out, c->d_strand, c->d_off,
+    void* ptrs[] = { c->d_comp, c->d_counters, c->d_seg_counts, c->d_lists[0], c->d_lists[1], c->d_lists[2], c->d_lists[3], c->d_in, c->d_out, c->d_strand, c->d_off,
                      c->d_idx, c->d_hash, c->d_keys, c->d_vals, c->d_scratch };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
