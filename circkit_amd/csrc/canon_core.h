@@ -153,22 +153,46 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
     const uint32_t lane = lane_id();
     const uint32_t nwf = n / S, r = n % S, nwv = nwf + (r ? 1u : 0u);
     uint32_t bad = 0;
-    for (uint32_t w = lane; w < nwv; w += 64) {
-        const bool tail = w >= nwf;
-        // tail words read the last / first S bytes of the record (in bounds: n >= 3S) and are shifted up
-        const uint32_t fa = tail ? n - S : w * S;
-        const uint32_t ra = tail ? 0u : n - S * (w + 1);
-        const uint32_t sh = tail ? (S - r) * BITS : 0u;
-        uint32_t f, c;
-        if (BITS == 2) {
-            f = pack2_fwd(load16(src + fa), bad);
-            c = pack2_rc(load16(src + ra));
-        } else {
-            f = pack4_fwd(load4(src + fa), load4(src + fa + 4), bad);
-            c = pack4_rc(load4(src + ra), load4(src + ra + 4));
+    // Rows of 64 words, four rows per trip with all eight 16-byte loads issued before the first is consumed:
+    // a long record is otherwise one exposed HBM round trip per row (measured: tier B of BASELINE config 4 spent
+    // 61 % of its wave cycles in s_waitcnt with the VALU 20 % busy).
+    constexpr int U = 4;
+    for (uint32_t w0 = lane; w0 < nwv; w0 += 64 * U) {
+        u32x4 vf[U], vc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w = w0 + 64 * u;
+            if (w < nwv) {
+                const bool tail = w >= nwf;
+                // tail words read the last / first S bytes of the record (in bounds: n >= 3S) and are shifted up
+                const uint32_t fa = tail ? n - S : w * S;
+                const uint32_t ra = tail ? 0u : n - S * (w + 1);
+                if (BITS == 2) {
+                    vf[u] = load16(src + fa);
+                    vc[u] = load16(src + ra);
+                } else {
+                    vf[u] = u32x4{ load4(src + fa), load4(src + fa + 4), 0, 0 };
+                    vc[u] = u32x4{ load4(src + ra), load4(src + ra + 4), 0, 0 };
+                }
+            }
         }
-        Ef[w] = f << sh;
-        Er[w] = c << sh;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w = w0 + 64 * u;
+            if (w < nwv) {
+                const uint32_t sh = w >= nwf ? (S - r) * BITS : 0u;
+                uint32_t f, c;
+                if (BITS == 2) {
+                    f = pack2_fwd(vf[u], bad);
+                    c = pack2_rc(vc[u]);
+                } else {
+                    f = pack4_fwd(vf[u].x, vf[u].y, bad);
+                    c = pack4_rc(vc[u].x, vc[u].y);
+                }
+                Ef[w] = f << sh;
+                Er[w] = c << sh;
+            }
+        }
     }
     const bool ok = ballot(bad != 0) == 0;
     wave_sync();
