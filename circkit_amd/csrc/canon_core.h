@@ -31,7 +31,8 @@ struct CanonArgs {
     uint8_t* out_bytes;          // nullable; same offsets as the input
     uint32_t* out_index;         // nullable
     uint8_t* out_strand;         // nullable
-    uint64_t* out_hash;          // nullable; XXH3-64 of the canonical bytes
+    uint64_t* out_hash;          // nullable; XXH3-64 of the canonical bytes (written by the streaming kernel where it can)
+    uint8_t* hashed;             // [n_records] set to 1 where out_hash was written; the xxh3 pass does the rest
     // Work lists are SEGMENTED per producing workgroup: a workgroup appends the records it cannot take to its own
     // segment with an LDS counter and publishes the count when it ends -- no global atomics on the data path
     // (one shared counter serialises at ~10 ns per append: 7 ms for the 760k deferrals of BASELINE config 4).
@@ -46,6 +47,7 @@ struct CanonArgs {
     uint32_t slice_dw;           // LDS dwords available to one wave
     uint32_t flags;              // CK_FLAG_*
 };
+constexpr uint32_t CK_FLAG_BYTES_OPTIONAL = 2u;   // out_bytes is a scratch: only records whose hash is NOT fused need their bytes
 constexpr uint32_t CK_FLAG_FWD_ONLY = 1u;   // lmsr(): forward strand only (lib/src/canonicalize.rs:41-47)
 
 struct RotResult { uint32_t idx; uint32_t period; };

@@ -8,6 +8,7 @@
 // LDS kernel of canon_core.h.  Same reference functions as there (lib/src/canonicalize.rs:5-63).
 #pragma once
 #include "canon_core.h"
+#include "xxh3_core.h"
 
 namespace ck {
 
@@ -98,11 +99,79 @@ CK_DEV u32x4 fast_decode(const uint32_t* lut, uint32_t w)
     return u32x4{ lut[w >> 24], lut[(w >> 16) & 0xFF], lut[(w >> 8) & 0xFF], lut[w & 0xFF] };
 }
 
+// ---- XXH3-64 fused into the streaming kernel (records of 241..1008 bytes: one 1024-byte block, no scramble) ----
+// Replaces `xxh3_64(canonicalized)` (src/uniq.rs:45) without re-reading the canonical bytes: lane t already holds
+// bytes [16t, 16t+16) of the output = cell (stripe t>>2, accumulator pair t&3) of XXH3's long-input loop.
+// Everything that depends only on the lane is computed once per wave.
+struct FastHashConst {
+    uint64_t k0, k1;    // secret words of this lane's cell:            offset 8*(t>>2) + 16*(t&3), +8
+    uint64_t l0, l1;    // secret words of the last stripe, pair t&3:   offset 121 + 16*(t&3), +8
+    uint64_t m0, m1;    // secret words of the final merge, pair t&3:   offset 11 + 16*(t&3), +8
+    uint64_t i0, i1;    // accumulator initial values of pair t&3
+};
+CK_DEV FastHashConst fast_hash_const()
+{
+    const uint32_t t = lane_id(), j = t & 3;
+    FastHashConst h;
+    h.k0 = xsec64(8 * (t >> 2) + 16 * j); h.k1 = xsec64(8 * (t >> 2) + 16 * j + 8);
+    h.l0 = xsec64(121 + 16 * j); h.l1 = xsec64(129 + 16 * j);
+    h.m0 = xsec64(11 + 16 * j); h.m1 = xsec64(19 + 16 * j);
+    h.i0 = j == 0 ? XP32_3 : j == 1 ? XP64_2 : j == 2 ? XP64_4 : XP64_5;
+    h.i1 = j == 0 ? XP64_1 : j == 1 ? XP64_3 : j == 2 ? XP32_2 : XP32_1;
+    return h;
+}
+template <int N>
+CK_DEV uint64_t row_shr_add64(uint64_t v)
+{
+    const uint64_t o = ((uint64_t)dpp_row_shr<N>((uint32_t)(v >> 32)) << 32) | dpp_row_shr<N>((uint32_t)v);
+    return v + o;
+}
+CK_DEV uint64_t shfl_xor_add64(uint64_t v, uint32_t m)
+{
+    const uint32_t src = lane_id() ^ m;
+    return v + (((uint64_t)shfl((uint32_t)(v >> 32), src) << 32) | shfl((uint32_t)v, src));
+}
+// `cell` = this lane's 16 canonical bytes [16t, 16t+16) (valid for t < 4*stripes); E / idx = winning strand and
+// rotation; returns the hash (same value in every lane).
+CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 cell, uint32_t E, uint32_t idx, uint32_t n)
+{
+    const uint32_t t = lane_id();
+    const uint32_t stripes = (n - 1) >> 6;                       // full 64-byte stripes before the last one
+    uint64_t c0 = 0, c1 = 0;
+    {
+        const uint64_t d0 = ((uint64_t)cell.y << 32) | cell.x, d1 = ((uint64_t)cell.w << 32) | cell.z;
+        const uint64_t x0 = d0 ^ hc.k0, x1 = d1 ^ hc.k1;
+        const bool on = t < 4 * stripes;
+        c0 = on ? d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32) : 0;
+        c1 = on ? d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32) : 0;
+    }
+    // sum over the 16 stripes: lanes t, t+4, t+8, t+12 inside a row (DPP), then the four rows (LDS crossbar)
+    c0 = row_shr_add64<4>(c0); c1 = row_shr_add64<4>(c1);
+    c0 = row_shr_add64<8>(c0); c1 = row_shr_add64<8>(c1);        // lanes 12..15 of each row: row sums of pair t&3
+    c0 = shfl_xor_add64(c0, 16); c1 = shfl_xor_add64(c1, 16);
+    c0 = shfl_xor_add64(c0, 32); c1 = shfl_xor_add64(c1, 32);
+    uint64_t a0 = hc.i0 + c0, a1 = hc.i1 + c1;                   // meaningful in lanes with (t & 15) >= 12
+    {   // last stripe: the final 64 bytes, pair t&3 = bytes [n-64+16j, n-48+16j)
+        const uint32_t w = reg_sym_word(E, idx + (n - 64) + 16 * (t & 3), n);
+        const u32x4 b = fast_decode(lut, w);
+        const uint64_t d0 = ((uint64_t)b.y << 32) | b.x, d1 = ((uint64_t)b.w << 32) | b.z;
+        const uint64_t x0 = d0 ^ hc.l0, x1 = d1 ^ hc.l1;
+        a0 += d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32);
+        a1 += d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32);
+    }
+    uint64_t r = xfold(a0 ^ hc.m0, a1 ^ hc.m1);                  // merge: sum over the four pairs (one quad)
+    r += ((uint64_t)dpp_quad_xor1((uint32_t)(r >> 32)) << 32) | dpp_quad_xor1((uint32_t)r);
+    r += ((uint64_t)dpp_quad_xor2((uint32_t)(r >> 32)) << 32) | dpp_quad_xor2((uint32_t)r);
+    const uint64_t h = xaval3((uint64_t)n * XP64_1 + r);
+    return ((uint64_t)readlane((uint32_t)(h >> 32), 15) << 32) | readlane((uint32_t)h, 15);
+}
+
 // Canonicalizes one eligible record held as 16 bytes per lane; returns false (nothing written) when the
 // record must go to the general kernel: a byte outside ACGT, or a minimal key that is not unique.
 // Single exit: the rare failures are folded into one flag instead of early returns, which keeps the
 // scalar unit's branch / mask bookkeeping off the hot path.
-CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uint64_t off, uint32_t n, u32x4 bytes)
+CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
+                         u32x4 bytes)
 {
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
@@ -152,12 +221,21 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint32_t rec, 
             fwd = k < n && readlane(wa, l) < readlane(wb, l);
         }
     }
-    if (a.out_bytes) {
+    {
         // every lane stores a full 16 bytes: the last lane's window is pulled back to end exactly at n, so it
         // overlaps its neighbour's with identical bytes -- one store instruction, no partial-store branches
         const uint32_t o = 16 * t + 16 <= n ? 16 * t : n - 16;
-        const uint32_t w = reg_sym_word(fwd ? F : C, (fwd ? iF : iC) + o, n);
-        if (valid) store16(a.out_bytes + off + o, fast_decode(lut, w));
+        const uint32_t E = fwd ? F : C, idx = fwd ? iF : iC;
+        const bool hash = a.out_hash != nullptr && n > 240;             // XXH3's long-input path; shorter: xxh3 pass
+        const bool store = a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL));
+        if (store || hash) {
+            const u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
+            if (store && valid) store16(a.out_bytes + off + o, cell);
+            if (hash) {
+                const uint64_t h = fast_hash(hc, lut, cell, E, idx, n);
+                if (t == 0) { a.out_hash[rec] = h; a.hashed[rec] = 1; }
+            }
+        }
     }
     if (t == 0) {
         // unique minimum => period n; iC + iF < 2n
@@ -180,7 +258,7 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, uint32_t rec, 
 struct FastSlot { uint64_t off; uint32_t n; };
 
 template <int NB>
-CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t* blk_count, uint32_t block, uint32_t rec,
+CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t* blk_count, uint32_t block, uint32_t rec,
                       uint32_t last, uint32_t stride, const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill,
                       uint32_t* fill_buf)
 {
@@ -192,9 +270,9 @@ CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, uint32_t* blk_cou
     fill.off = o0;
     fill.n = (uint32_t)(o1 - o0);
     fast_issue(a, o0, fill.n, fill_buf);
-    if (!(fast_eligible(cur.n) && fast_process(a, lut, rec, cur.off, cur.n, fast_fetch(cur_buf))))
+    if (!(fast_eligible(cur.n) && fast_process(a, lut, hc, rec, cur.off, cur.n, fast_fetch(cur_buf))))
         defer_record(a, blk_count, block, rec);
-    if (a.out_bytes) vmem_wait<2 * D - 1>(); else vmem_wait<D - 1>();
+    if (a.out_bytes || a.out_hash) vmem_wait<2 * D - 1>(); else vmem_wait<D - 1>();
 }
 
 template <int NB>
@@ -206,6 +284,8 @@ CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32
     const uint32_t total = (uint32_t)a.n_records, stride = n_waves, last = total - 1;
     uint32_t rec = wave_id;
     if (rec >= total) return;
+    FastHashConst hc{};
+    if (a.out_hash) hc = fast_hash_const();
     FastSlot s[NB];
 #pragma unroll
     for (int i = 0; i < NB - 1; ++i) {      // prologue: records rec .. rec + (NB-2)*stride
@@ -220,7 +300,7 @@ CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32
         for (int i = 0; i < NB; ++i) {
             constexpr int dummy = 0; (void)dummy;
             const int f = (i + NB - 1) % NB;
-            fast_step<NB>(a, lut, blk_count, block, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f);
+            fast_step<NB>(a, lut, hc, blk_count, block, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f);
             rec += stride;
             if (rec >= total) return;
         }

@@ -62,11 +62,12 @@ __global__ __launch_bounds__(256, CK_FAST_WPE) void canon_fast_kernel(ck::CanonA
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).
 __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
-                                                   uint64_t* out)
+                                                   uint64_t* out, const uint8_t* hashed)
 {
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
     for (uint64_t r = wave; r < n_records; r += n_waves) {
+        if (hashed && hashed[r]) continue;               // the streaming kernel already hashed this record
         const uint64_t off = offsets[r];
         const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
         if (ck::lane_id() == 0) out[r] = h;
@@ -213,6 +214,7 @@ struct circkit_ctx {
     uint64_t* d_off = nullptr; uint32_t* d_idx = nullptr; uint64_t* d_hash = nullptr;
     uint64_t cap_bytes = 0, cap_rec = 0;
     uint8_t* d_scratch = nullptr; uint64_t cap_scratch = 0;   // canonical bytes of hash-only batches
+    uint8_t* d_hashed = nullptr; uint64_t cap_hashed = 0;     // per record: hash already written by the streaming kernel
     // uniq table
     unsigned long long *d_keys = nullptr, *d_vals = nullptr;
     uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
@@ -280,12 +282,21 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             c->cap_scratch = lastoff + 64;
         }
         d_out = c->d_scratch;       // indexed by the same absolute offsets as the input
+        flags |= ck::CK_FLAG_BYTES_OPTIONAL;   // ...and only needed for records whose hash is not fused
+    }
+    if (d_hash) {
+        if (n > c->cap_hashed) {
+            if (c->d_hashed) { (void)hipFree(c->d_hashed); c->d_hashed = nullptr; c->cap_hashed = 0; }
+            CK_HIP(c, hipMalloc(&c->d_hashed, n + n / 8 + 64));
+            c->cap_hashed = n + n / 8 + 64;
+        }
+        CK_HIP(c, hipMemsetAsync(c->d_hashed, 0, n, c->stream));
     }
     CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
-    a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr;
+    a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = d_hash; a.hashed = c->d_hashed;
     a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags | c->debug_flags;
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
     a.list = nullptr; a.list_count = nullptr;
@@ -310,7 +321,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         seg_cap = spb * seg_cap;
     }
     if (d_hash) {
-        hipLaunchKernelGGL(xxh3_kernel, dim3(G), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash);
+        hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed);
     }
     CK_HIP(c, hipEventRecord(c->ev1, c->stream));
     CK_HIP(c, hipGetLastError());
@@ -423,7 +434,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void* ptrs[] = { c->d_comp, c->d_counters, c->d_seg_counts, c->d_lists[0], c->d_lists[1], c->d_lists[2], c->d_lists[3], c->d_in, c->d_out, c->d_strand, c->d_off,
-                     c->d_idx, c->d_hash, c->d_keys, c->d_vals, c->d_scratch };
+                     c->d_idx, c->d_hash, c->d_keys, c->d_vals, c->d_scratch, c->d_hashed };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -547,7 +558,7 @@ int circkit_xxh3_64(circkit_ctx* c, const uint8_t* s, size_t n, uint64_t* out_ha
     uint64_t off[2] = { 0, (uint64_t)n };
     if (n) CK_HIP(c, hipMemcpyAsync(c->d_in, s, n, hipMemcpyHostToDevice, c->stream));
     CK_HIP(c, hipMemcpyAsync(c->d_off, off, 16, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, c->d_in, c->d_off, (uint64_t)1, c->d_hash);
+    hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, c->d_in, c->d_off, (uint64_t)1, c->d_hash, (const uint8_t*)nullptr);
     CK_HIP(c, hipMemcpyAsync(out_hash, c->d_hash, 8, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
     return CIRCKIT_OK;
@@ -561,7 +572,7 @@ int circkit_xxh3_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint
     CK_HIP(c, hipSetDevice(c->device));
     const uint64_t blocks = (n + 3) / 4;
     const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
-    hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_bytes, d_offsets, n, d_hash);
+    hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_bytes, d_offsets, n, d_hash, (const uint8_t*)nullptr);
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
 }

@@ -64,6 +64,15 @@ CK_DEV uint32_t wave_shl1(uint32_t v)
     asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=&v"(o) : "v"(v));
     return o;
 }
+// value of lane i-N of the same 16-lane row, 0 where that lane does not exist (DPP row_shr:N, bound_ctrl)
+template <int N>
+CK_DEV uint32_t dpp_row_shr(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xF, 0xF, true);
+}
+// value of lane i^1 / i^2 (quad_perm)
+CK_DEV uint32_t dpp_quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+CK_DEV uint32_t dpp_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }
 // Two independent wave-wide mins at once.  The two DPP chains are interleaved so each fills the other's
 // VALU->DPP wait states (2 needed; one comes from the sibling instruction, one from s_nop 0) and the
 // min is fused into the DPP instruction (hipcc emits v_mov_dpp + v_min otherwise).
@@ -229,6 +238,15 @@ CK_DEV uint64_t wave_sum_u64(uint64_t v)
     uint64_t s = 0; for (int i = 0; i < 64; ++i) s += all[i];
     return s;
 }
+template <int N>
+CK_DEV uint32_t dpp_row_shr(uint32_t v)
+{
+    uint64_t all[64]; emu::gather(v, all);
+    const uint32_t t = lane_id();
+    return (t & 15) >= (uint32_t)N ? (uint32_t)all[t - N] : 0u;
+}
+CK_DEV uint32_t dpp_quad_xor1(uint32_t v) { uint64_t all[64]; emu::gather(v, all); return (uint32_t)all[lane_id() ^ 1]; }
+CK_DEV uint32_t dpp_quad_xor2(uint32_t v) { uint64_t all[64]; emu::gather(v, all); return (uint32_t)all[lane_id() ^ 2]; }
 CK_DEV uint32_t wave_shl1(uint32_t v)
 {
     uint64_t all[64]; emu::gather(v, all);

@@ -107,12 +107,21 @@ void fast_body(void* p)
 }
 }
 
+namespace {
+struct HashLaunch { const uint8_t* p; uint32_t n; uint64_t out[64]; };
+void hash_body(void* q)
+{
+    HashLaunch* H = (HashLaunch*)q;
+    H->out[ck::lane_id()] = ck::xxh3_64_wave(H->p, H->n);
+}
+}
+
 // Same launch sequence as the host library: streaming kernel over everything (workgroups of 4 waves, each with
 // its own deferral segment), then one LDS tier over the segmented list.  n_waves is rounded up to whole workgroups.
 extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                       uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
                                       uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
-                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast)
+                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast, uint32_t* n_fused_hash)
 {
     uint8_t comp[256];
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
@@ -128,6 +137,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a = ck::CanonArgs{};
     L.a.bytes = bytes; L.a.offsets = offsets; L.a.n_records = n_records;
     L.a.out_bytes = out_bytes; L.a.out_index = out_index; L.a.out_strand = out_strand; L.a.out_hash = out_hash;
+    std::vector<uint8_t> hashed(n_records + 1, 0);
+    L.a.hashed = hashed.data();
     L.a.status = &status; L.a.comp_lut = comp; L.a.flags = flags;
     L.a.defer_list = list_f.data(); L.a.defer_count = cnt_f.data(); L.a.out_seg_cap = cap;
     L.lds = lds.data(); L.lut = lut; L.nblocks = G;
@@ -148,16 +159,16 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
         cnt_a[b] = blk; total_a += blk;
     }
     if (n_deferred) *n_deferred = total_a;
+    if (out_hash) {     // the xxh3 pass for whatever the streaming kernel did not hash
+        for (uint64_t r = 0; r < n_records; ++r) {
+            if (hashed[r]) continue;
+            HashLaunch H{ out_bytes + offsets[r], (uint32_t)(offsets[r + 1] - offsets[r]), {0} };
+            ck::emu::run_wave(hash_body, &H);
+            out_hash[r] = H.out[0];
+        }
+    }
+    if (n_fused_hash) { *n_fused_hash = 0; for (uint64_t r = 0; r < n_records; ++r) *n_fused_hash += hashed[r]; }
     return (int)status;
-}
-
-namespace {
-struct HashLaunch { const uint8_t* p; uint32_t n; uint64_t out[64]; };
-void hash_body(void* q)
-{
-    HashLaunch* H = (HashLaunch*)q;
-    H->out[ck::lane_id()] = ck::xxh3_64_wave(H->p, H->n);
-}
 }
 
 extern "C" uint64_t emu_xxh3_64(const uint8_t* p, uint32_t n)

@@ -20,6 +20,7 @@ def build():
 
 _lib = None
 last_fast_count = 0
+last_fused_hash_count = 0
 
 
 def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0):
@@ -27,7 +28,7 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.emu_canonicalize_batch.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4 + \
-            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
@@ -39,11 +40,13 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     hs = np.zeros(max(n, 1), dtype=np.uint64)
     ndef = ctypes.c_uint32(0)
     nfast = ctypes.c_uint32(0)
+    nfused = ctypes.c_uint32(0)
     st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data, idx.ctypes.data,
                                      strand.ctypes.data, hs.ctypes.data if want_hash else None,
-                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast))
-    global last_fast_count
+                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused))
+    global last_fast_count, last_fused_hash_count
     last_fast_count = nfast.value
+    last_fused_hash_count = nfused.value
     assert (out[len(data):] == 0x3F).all(), "kernel wrote past the end of the output buffer"
     return out[:len(data)], idx[:n], strand[:n], hs[:n], st, ndef.value
 

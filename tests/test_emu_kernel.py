@@ -90,3 +90,16 @@ def test_streaming_kernel_takes_the_headline_records():
     assert emu.last_fast_count == len(seqs)
     emu.canonicalize_batch(*seqsets.pack([b"ACGTN" * 200, b"A" * 500, b"ACGT" * 10, b"ACGT" * 300]))
     assert emu.last_fast_count == 0     # N, repeats, too short, too long -> general kernel
+
+
+def test_fused_xxh3_matches_oracle():
+    """XXH3 computed inside the streaming kernel (records of 241..1008 bases) and by the xxh3 pass (the rest)."""
+    seqs = seqsets.random_mixed(36, 120, 241, 1008) + seqsets.random_mixed(37, 40, 1, 300) + \
+        seqsets.random_mixed(38, 20, 900, 1100) + [b"ACGT" * 250, b"ACGTN" * 100] + \
+        [seqsets.rand_seq(__import__("random").Random(n), n) for n in (241, 255, 256, 257, 319, 320, 321, 1000, 1007, 1008)]
+    data, offs = seqsets.pack(seqs)
+    out, idx, strand, hs, status, ndef = emu.canonicalize_batch(data, offs, slice_dw=4096, want_hash=True)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True)
+    assert np.array_equal(out, exp)
+    assert np.array_equal(hs, exp_h)
+    assert emu.last_fused_hash_count >= 130     # the 241..1008-base pure-ACGT records with a unique minimum
