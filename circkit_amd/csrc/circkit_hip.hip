@@ -201,7 +201,6 @@ struct circkit_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    uint32_t debug_flags = 0;            // CIRCKIT_DEBUG_FLAGS: timing ablations of the streaming kernel (bits 8..)
     std::string err;
     uint8_t* d_comp = nullptr;
     uint32_t* d_counters = nullptr;      // [3] unprocessed records; [4] uniq table overflow
@@ -297,7 +296,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = d_hash; a.hashed = c->d_hashed;
-    a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags | c->debug_flags;
+    a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
@@ -407,7 +406,6 @@ int circkit_ctx_create(int device, circkit_ctx** out)
         return CIRCKIT_ERR_NO_DEVICE;
     circkit_ctx* c = new circkit_ctx();
     c->device = device;
-    if (const char* e = getenv("CIRCKIT_DEBUG_FLAGS")) c->debug_flags = (uint32_t)strtoul(e, nullptr, 0) << 8;
     *out = c;   // handed out even on failure below so the caller can read last_error, then destroy
     CK_HIP(c, hipSetDevice(device));
     CK_HIP(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
