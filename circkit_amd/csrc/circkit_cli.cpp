@@ -17,7 +17,10 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/circkit.h"
@@ -47,7 +50,7 @@ void usage(FILE* f)
             "    -o      output FASTA path; .gz/.bz2/.xz/.zst compress [default: stdout]\n"
             "    -c      uniq: output canonicalized sequences (aliases --norm --canon)\n"
             "    --table uniq: CSV (TSV for .tsv) of id,duplicate_id\n"
-            "    -t      host threads (accepted for compatibility; records are batched to the GPU)\n"
+            "    -t      host parser threads [default: logical cores, at most 16]\n"
             "    --device <N>  GPU index [default: 0]\n");
 }
 
@@ -167,6 +170,51 @@ void check(circkit_ctx* ctx, int rc)
     if (rc != CIRCKIT_OK) die(std::string("GPU path failed: ") + circkit_last_error(ctx));
 }
 
+// ---- the pipeline ------------------------------------------------------------------------------------------
+// reader -> parser pool -> GPU -> writer over a ring of chunk slots.  Mirrors seq_io's parallel_fasta shape
+// (one reader, `--threads` workers, results consumed in input order: src/canonicalize.rs:17-45) with the worker
+// closure replaced by "parse + normalize + pack" on the host and ONE GPU batch call per chunk.
+enum State { FREE, READ, PARSED, COMPUTED };
+
+struct Slot {
+    State state = FREE;
+    long seq = -1;                              // sequence number of the chunk this slot currently holds
+    std::vector<uint8_t> text;
+    size_t len = 0;
+    bool first = false;
+    ckhost::Batch batch;
+    std::vector<uint8_t> canon;
+    std::vector<uint64_t> hash, first_seen;
+    uint64_t base = 0;
+};
+
+struct Pipeline {
+    static constexpr int K = 6;                 // chunk slots in flight
+    static constexpr size_t CHUNK = 64u << 20;  // text bytes per chunk (one GPU batch)
+    Slot slot[K];
+    std::mutex m;
+    std::condition_variable cv;
+    long n_chunks = -1;                         // set by the reader at EOF
+    long next_parse = 0;                        // next chunk sequence number a parser may take
+
+    void set(long seq, State st)
+    {
+        { std::lock_guard<std::mutex> g(m); slot[seq % K].state = st; if (st == READ) slot[seq % K].seq = seq; }
+        cv.notify_all();
+    }
+    // waits until chunk `seq` (not an older tenant of the same slot) reaches `st`; false when the stream ended
+    // before that chunk.  FREE is waited for by the reader only: any FREE slot will do.
+    bool wait(long seq, State st)
+    {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] {
+            const Slot& s = slot[seq % K];
+            return (s.state == st && (st == FREE || s.seq == seq)) || (n_chunks >= 0 && seq >= n_chunks);
+        });
+        return !(n_chunks >= 0 && seq >= n_chunks);
+    }
+};
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -185,79 +233,140 @@ int main(int argc, char** argv)
     const int rc = circkit_ctx_create(opt.device, &ctx);
     if (rc != CIRCKIT_OK) die(std::string("no usable MI355X GPU (device ") + std::to_string(opt.device) + "): " +
                                (ctx ? circkit_last_error(ctx) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
-
     const bool uniq = opt.cmd == "uniq";
-    const size_t CHUNK = 256u << 20;                  // text per GPU batch
-    std::vector<uint8_t> text;
-    size_t have = 0;
-    bool eof = false, first = true, table_header = false;
-    ckhost::Batch b;
-    std::vector<uint8_t> canon;
-    std::vector<uint64_t> hash, first_seen;
-    std::vector<std::string> ids;                     // uniq: id of every kept record, by global index
-    std::vector<uint64_t> kept_slot;                  // global index -> slot in ids (or ~0)
-    uint64_t base = 0;
-    std::string err, line;
+    const bool want_bytes = !uniq || opt.canonicalize;
+    int n_parsers = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();   // src/commands.rs:120-123
+    if (n_parsers < 1) n_parsers = 1;
+    if (n_parsers > 16) n_parsers = 16;
+    static Pipeline P;
 
-    while (!eof || have) {
-        // fill the chunk; grow it when a single record does not fit
-        if (text.size() < have + CHUNK) text.resize(have + CHUNK);
-        while (!eof && have < text.size()) {
-            const size_t got = fread(text.data() + have, 1, text.size() - have, in.f);
-            if (got == 0) { if (ferror(in.f)) die("failed to read the input"); eof = true; }
-            have += got;
-        }
-        size_t consumed = 0;
-        if (!ckhost::parse_chunk(text.data(), have, first, eof, b, &consumed, err)) die(err);
-        if (consumed == 0 && !eof) { text.resize(text.size() * 2); continue; }   // one record longer than the chunk
-        first = false;
-        const uint64_t n = b.n();
-        if (n) {
-            const uint64_t total = b.offsets[n];
-            const bool want_bytes = !uniq || opt.canonicalize;
-            canon.resize(total + 64);
-            if (uniq) hash.resize(n);
-            check(ctx, circkit_canonicalize_batch(ctx, b.bytes.data(), b.offsets.data(), n, want_bytes ? canon.data() : nullptr,
-                                                  nullptr, nullptr, uniq ? hash.data() : nullptr));
-            if (uniq) {
-                first_seen.resize(n);
-                check(ctx, circkit_uniq_first_seen(ctx, hash.data(), n, base, first_seen.data()));
-                if (table) kept_slot.resize(base + n, ~0ull);
+    // ---- stage 1: reader.  Cuts every chunk at a record start so the parsers never see a partial record.
+    std::thread reader([&] {
+        std::vector<uint8_t> carry;
+        bool eof = false;
+        long seq = 0;
+        while (!eof || !carry.empty()) {
+            P.wait(seq, FREE);
+            Slot& s = P.slot[seq % Pipeline::K];
+            size_t have = carry.size();
+            if (s.text.size() < have + Pipeline::CHUNK) s.text.resize(have + Pipeline::CHUNK);
+            memcpy(s.text.data(), carry.data(), have);
+            carry.clear();
+            size_t cut = 0;
+            for (;;) {
+                while (!eof && have < s.text.size()) {
+                    const size_t got = fread(s.text.data() + have, 1, s.text.size() - have, in.f);
+                    if (got == 0) { if (ferror(in.f)) die("failed to read the input"); eof = true; }
+                    have += got;
+                }
+                if (eof) { cut = have; break; }
+                // last record start ("\n>") in the buffer: everything before it is complete
+                size_t k = have;
+                while (k > 1) {
+                    const void* g = memrchr(s.text.data() + 1, '>', k - 1);
+                    if (!g) { k = 0; break; }
+                    const size_t gi = (const uint8_t*)g - s.text.data();
+                    if (s.text[gi - 1] == '\n') { cut = gi; break; }
+                    k = gi;
+                }
+                if (cut) break;
+                s.text.resize(s.text.size() * 2);          // one record longer than the chunk: keep reading
             }
-            for (uint64_t i = 0; i < n; ++i) {
-                const ckhost::Span h = b.head[i];
-                bool keep = true;
-                if (uniq) {
-                    keep = first_seen[i] == base + i;
-                    const ckhost::Span id = ckhost::record_id(text.data(), h);
-                    if (keep) {
-                        if (table) { kept_slot[base + i] = ids.size(); ids.emplace_back((const char*)text.data() + id.off, id.len); }
-                    } else if (table) {                                        // src/uniq.rs:63-70
+            carry.assign(s.text.begin() + cut, s.text.begin() + have);
+            s.len = cut;
+            s.first = seq == 0;
+            if (cut == 0 && eof && carry.empty() && seq > 0) break;
+            P.set(seq, READ);
+            ++seq;
+        }
+        { std::lock_guard<std::mutex> g(P.m); P.n_chunks = seq; }
+        P.cv.notify_all();
+    });
+
+    // ---- stage 2: parsers (FASTA record boundaries + needletail normalize + CSR pack), any order
+    std::vector<std::thread> parsers;
+    for (int t = 0; t < n_parsers; ++t)
+        parsers.emplace_back([&] {
+            for (;;) {
+                long seq;
+                { std::lock_guard<std::mutex> g(P.m); seq = P.next_parse++; }
+                if (!P.wait(seq, READ)) return;
+                Slot& s = P.slot[seq % Pipeline::K];
+                std::string err;
+                size_t consumed = 0;
+                if (!ckhost::parse_chunk(s.text.data(), s.len, s.first, true, s.batch, &consumed, err)) die(err);
+                P.set(seq, PARSED);
+            }
+        });
+
+    // ---- stage 3: GPU, in input order (one ctx, one thread): canonical bytes / hashes / first-seen
+    std::thread gpu([&] {
+        uint64_t base = 0;
+        for (long seq = 0; P.wait(seq, PARSED); ++seq) {
+            Slot& s = P.slot[seq % Pipeline::K];
+            const uint64_t n = s.batch.n();
+            s.base = base;
+            if (n) {
+                const uint64_t total = s.batch.offsets[n];
+                if (want_bytes) s.canon.resize(total + 64);
+                if (uniq) { s.hash.resize(n); s.first_seen.resize(n); }
+                check(ctx, circkit_canonicalize_batch(ctx, s.batch.bytes.data(), s.batch.offsets.data(), n,
+                                                      want_bytes ? s.canon.data() : nullptr, nullptr, nullptr,
+                                                      uniq ? s.hash.data() : nullptr));
+                if (uniq) check(ctx, circkit_uniq_first_seen(ctx, s.hash.data(), n, base, s.first_seen.data()));
+                base += n;
+            }
+            P.set(seq, COMPUTED);
+        }
+    });
+
+    // ---- stage 4: writer, in input order (this thread)
+    std::vector<std::string> ids;                     // uniq --table: id of every kept record ...
+    std::vector<uint64_t> kept_slot;                  // ... found through global index -> slot in ids
+    bool table_header = false;
+    std::string line;
+    std::vector<char> obuf;
+    for (long seq = 0; P.wait(seq, COMPUTED); ++seq) {
+        Slot& s = P.slot[seq % Pipeline::K];
+        const ckhost::Batch& b = s.batch;
+        const uint8_t* text = s.text.data();
+        const uint64_t n = b.n();
+        if (uniq && table) kept_slot.resize(s.base + n, ~0ull);
+        obuf.clear();
+        obuf.reserve(s.len + 2 * n + 64);
+        for (uint64_t i = 0; i < n; ++i) {
+            const ckhost::Span h = b.head[i];
+            if (uniq) {
+                const bool keep = s.first_seen[i] == s.base + i;
+                if (table) {
+                    const ckhost::Span id = ckhost::record_id(text, h);
+                    if (keep) { kept_slot[s.base + i] = ids.size(); ids.emplace_back((const char*)text + id.off, id.len); }
+                    else {                                                     // src/uniq.rs:63-70
                         line.clear();
                         if (!table_header) { line += "id"; line += delim; line += "duplicate_id\n"; table_header = true; }
-                        const std::string& fid = ids[kept_slot[first_seen[i]]];
+                        const std::string& fid = ids[kept_slot[s.first_seen[i]]];
                         ckhost::csv_field(line, (const uint8_t*)fid.data(), fid.size(), delim);
                         line += delim;
-                        ckhost::csv_field(line, text.data() + id.off, id.len, delim);
+                        ckhost::csv_field(line, text + id.off, id.len, delim);
                         line += '\n';
                         fwrite(line.data(), 1, line.size(), table);
                     }
                 }
                 if (!keep) continue;
-                fputc('>', out.f);                                             // src/canonicalize.rs:33-37, src/uniq.rs:50-61
-                fwrite(text.data() + h.off, 1, h.len, out.f);
-                fputc('\n', out.f);
-                if (want_bytes) fwrite(canon.data() + b.offsets[i], 1, b.offsets[i + 1] - b.offsets[i], out.f);
-                else fwrite(text.data() + b.raw[i].off, 1, b.raw[i].len, out.f);
-                fputc('\n', out.f);
             }
-            if (ferror(out.f)) die("failed to write output");
-            base += n;
+            obuf.push_back('>');                                               // src/canonicalize.rs:33-37, src/uniq.rs:50-61
+            obuf.insert(obuf.end(), text + h.off, text + h.off + h.len);
+            obuf.push_back('\n');
+            if (want_bytes) obuf.insert(obuf.end(), s.canon.data() + b.offsets[i], s.canon.data() + b.offsets[i + 1]);
+            else obuf.insert(obuf.end(), text + b.raw[i].off, text + b.raw[i].off + b.raw[i].len);
+            obuf.push_back('\n');
         }
-        memmove(text.data(), text.data() + consumed, have - consumed);
-        have -= consumed;
-        if (eof && consumed == 0 && have) die("FASTA parse error: trailing bytes could not be parsed");
+        if (!obuf.empty() && fwrite(obuf.data(), 1, obuf.size(), out.f) != obuf.size()) die("failed to write output");
+        P.set(seq, FREE);
     }
+    reader.join();
+    for (auto& t : parsers) t.join();
+    gpu.join();
     close_output(out);
     if (table) fclose(table);
     if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }

@@ -13,7 +13,7 @@ with open("/dev/shm/in.fasta", "wb") as f:
         f.write(b"".join(rows))
 PY
 ls -la /dev/shm/in.fasta
-for i in 1 2; do s=$(date +%s.%N); $R/circkit_amd/circkit canonicalize /dev/shm/in.fasta -o /dev/shm/out.fasta; e=$(date +%s.%N); python3 -c "print('canonicalize: %.3f s wall' % ($e - $s))"; done
-s=$(date +%s.%N); $R/circkit_amd/circkit uniq -c /dev/shm/in.fasta -o /dev/shm/out2.fasta --table /dev/shm/t.csv; e=$(date +%s.%N); python3 -c "print('uniq -c: %.3f s wall' % ($e - $s))"
+for i in 1 2; do s=$(date +%s.%N); CIRCKIT_CLI_TIMING=1 $R/circkit_amd/circkit canonicalize /dev/shm/in.fasta -o /dev/shm/out.fasta; e=$(date +%s.%N); python3 -c "print('canonicalize: %.3f s wall' % ($e - $s))"; done
+s=$(date +%s.%N); CIRCKIT_CLI_TIMING=1 $R/circkit_amd/circkit uniq -c /dev/shm/in.fasta -o /dev/shm/out2.fasta --table /dev/shm/t.csv; e=$(date +%s.%N); python3 -c "print('uniq -c: %.3f s wall' % ($e - $s))"
 ls -la /dev/shm/out.fasta /dev/shm/out2.fasta /dev/shm/t.csv
 rm -f /dev/shm/in.fasta /dev/shm/out.fasta /dev/shm/out2.fasta /dev/shm/t.csv
