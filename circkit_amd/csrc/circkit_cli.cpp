@@ -37,7 +37,8 @@ struct Options {
 [[noreturn]] void die(const std::string& msg)
 {
     fprintf(stderr, "Error: %s\n", msg.c_str());     // anyhow's `Error: ...` on stderr, exit code 1 (src/main.rs:13,39)
-    exit(1);
+    fflush(stderr);
+    _exit(1);      // not exit(): other pipeline threads may be blocked on objects that static destruction would tear down
 }
 
 void usage(FILE* f)
