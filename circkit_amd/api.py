@@ -34,6 +34,8 @@ SIGNATURES = {
     "circkit_lmsr_batch_device": (_i, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "circkit_xxh3_batch_device": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "circkit_canonicalize_batch": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "circkit_host_alloc": (_vp, [_sz]),
+    "circkit_host_free": (None, [_vp]),
     "circkit_lmsr_index": (_i, [_vp, _vp, _sz, ctypes.POINTER(_sz)]),
     "circkit_lmsr": (_i, [_vp, _vp, _sz, _vp]),
     "circkit_canonicalize": (_i, [_vp, _vp, _sz, _vp]),

@@ -15,9 +15,13 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <condition_variable>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -98,6 +102,8 @@ std::string shell_quote(const std::string& s)
 struct Input {
     FILE* f = nullptr;
     bool piped = false;
+    const uint8_t* map = nullptr;      // regular uncompressed file: mapped, parsed in place (no read copy)
+    size_t map_len = 0;
 };
 
 const char* sniff(const uint8_t* m, size_t n)
@@ -122,7 +128,20 @@ Input open_input(const Options& o)
     uint8_t magic[6];
     const size_t got = fread(magic, 1, sizeof magic, f);
     const char* tool = sniff(magic, got);
-    if (!tool) { rewind(f); in.f = f; return in; }
+    if (!tool) {
+        rewind(f);
+        in.f = f;
+        struct stat st;
+        if (fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+            if (m != MAP_FAILED) {
+                (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                in.map = (const uint8_t*)m;
+                in.map_len = (size_t)st.st_size;
+            }
+        }
+        return in;
+    }
     fclose(f);
     const std::string cmd = std::string(tool) + " -dc " + shell_quote(o.input);
     in.f = popen(cmd.c_str(), "r");
@@ -180,11 +199,12 @@ enum State { FREE, READ, PARSED, COMPUTED };
 struct Slot {
     State state = FREE;
     long seq = -1;                              // sequence number of the chunk this slot currently holds
-    std::vector<uint8_t> text;
+    std::vector<uint8_t> own;                   // chunk text when the input is a stream
+    const uint8_t* text = nullptr;              // -> own, or into the mapped input file
     size_t len = 0;
     bool first = false;
-    ckhost::Batch batch;
-    std::vector<uint8_t> canon;
+    ckhost::Batch batch;                        // batch.bytes and canon live in pinned memory: DMA both ways
+    ckhost::ByteBuf canon;
     std::vector<uint64_t> hash, first_seen;
     uint64_t base = 0;
 };
@@ -241,44 +261,70 @@ int main(int argc, char** argv)
     if (n_parsers > 16) n_parsers = 16;
     static Pipeline P;
 
+    for (Slot& sl : P.slot) {
+        sl.batch.bytes.alloc = circkit_host_alloc; sl.batch.bytes.release = circkit_host_free;
+        sl.canon.alloc = circkit_host_alloc; sl.canon.release = circkit_host_free;
+    }
+    // last record start ("\n>") in buf[1, len): everything before it is complete.  0 = none.
+    auto last_record_start = [](const uint8_t* buf, size_t len) -> size_t {
+        size_t k = len;
+        while (k > 1) {
+            const void* g = memrchr(buf + 1, '>', k - 1);
+            if (!g) return 0;
+            const size_t gi = (const uint8_t*)g - buf;
+            if (buf[gi - 1] == '\n') return gi;
+            k = gi;
+        }
+        return 0;
+    };
     // ---- stage 1: reader.  Cuts every chunk at a record start so the parsers never see a partial record.
     std::thread reader([&] {
-        std::vector<uint8_t> carry;
-        bool eof = false;
         long seq = 0;
-        while (!eof || !carry.empty()) {
-            P.wait(seq, FREE);
-            Slot& s = P.slot[seq % Pipeline::K];
-            size_t have = carry.size();
-            if (s.text.size() < have + Pipeline::CHUNK) s.text.resize(have + Pipeline::CHUNK);
-            memcpy(s.text.data(), carry.data(), have);
-            carry.clear();
-            size_t cut = 0;
-            for (;;) {
-                while (!eof && have < s.text.size()) {
-                    const size_t got = fread(s.text.data() + have, 1, s.text.size() - have, in.f);
-                    if (got == 0) { if (ferror(in.f)) die("failed to read the input"); eof = true; }
-                    have += got;
+        if (in.map) {                               // mapped file: chunks are slices of the mapping
+            size_t pos = 0;
+            do {
+                P.wait(seq, FREE);
+                Slot& s = P.slot[seq % Pipeline::K];
+                size_t want = Pipeline::CHUNK, cut = 0;
+                for (;;) {
+                    if (pos + want >= in.map_len) { cut = in.map_len - pos; break; }
+                    cut = last_record_start(in.map + pos, want);
+                    if (cut) break;
+                    want *= 2;                      // one record longer than the chunk
                 }
-                if (eof) { cut = have; break; }
-                // last record start ("\n>") in the buffer: everything before it is complete
-                size_t k = have;
-                while (k > 1) {
-                    const void* g = memrchr(s.text.data() + 1, '>', k - 1);
-                    if (!g) { k = 0; break; }
-                    const size_t gi = (const uint8_t*)g - s.text.data();
-                    if (s.text[gi - 1] == '\n') { cut = gi; break; }
-                    k = gi;
+                s.text = in.map + pos; s.len = cut; s.first = seq == 0;
+                pos += cut;
+                P.set(seq, READ);
+                ++seq;
+            } while (pos < in.map_len);
+        } else {
+            std::vector<uint8_t> carry;
+            bool eof = false;
+            while (!eof || !carry.empty()) {
+                P.wait(seq, FREE);
+                Slot& s = P.slot[seq % Pipeline::K];
+                size_t have = carry.size();
+                if (s.own.size() < have + Pipeline::CHUNK) s.own.resize(have + Pipeline::CHUNK);
+                memcpy(s.own.data(), carry.data(), have);
+                carry.clear();
+                size_t cut = 0;
+                for (;;) {
+                    while (!eof && have < s.own.size()) {
+                        const size_t got = fread(s.own.data() + have, 1, s.own.size() - have, in.f);
+                        if (got == 0) { if (ferror(in.f)) die("failed to read the input"); eof = true; }
+                        have += got;
+                    }
+                    if (eof) { cut = have; break; }
+                    cut = last_record_start(s.own.data(), have);
+                    if (cut) break;
+                    s.own.resize(s.own.size() * 2);     // one record longer than the chunk: keep reading
                 }
-                if (cut) break;
-                s.text.resize(s.text.size() * 2);          // one record longer than the chunk: keep reading
+                carry.assign(s.own.begin() + cut, s.own.begin() + have);
+                s.text = s.own.data(); s.len = cut; s.first = seq == 0;
+                if (cut == 0 && eof && carry.empty() && seq > 0) break;
+                P.set(seq, READ);
+                ++seq;
             }
-            carry.assign(s.text.begin() + cut, s.text.begin() + have);
-            s.len = cut;
-            s.first = seq == 0;
-            if (cut == 0 && eof && carry.empty() && seq > 0) break;
-            P.set(seq, READ);
-            ++seq;
         }
         { std::lock_guard<std::mutex> g(P.m); P.n_chunks = seq; }
         P.cv.notify_all();
@@ -295,7 +341,7 @@ int main(int argc, char** argv)
                 Slot& s = P.slot[seq % Pipeline::K];
                 std::string err;
                 size_t consumed = 0;
-                if (!ckhost::parse_chunk(s.text.data(), s.len, s.first, true, s.batch, &consumed, err)) die(err);
+                if (!ckhost::parse_chunk(s.text, s.len, s.first, true, s.batch, &consumed, err)) die(err);
                 P.set(seq, PARSED);
             }
         });
@@ -309,7 +355,7 @@ int main(int argc, char** argv)
             s.base = base;
             if (n) {
                 const uint64_t total = s.batch.offsets[n];
-                if (want_bytes) s.canon.resize(total + 64);
+                if (want_bytes) { s.canon.len = 0; s.canon.reserve(total + 64); }
                 if (uniq) { s.hash.resize(n); s.first_seen.resize(n); }
                 check(ctx, circkit_canonicalize_batch(ctx, s.batch.bytes.data(), s.batch.offsets.data(), n,
                                                       want_bytes ? s.canon.data() : nullptr, nullptr, nullptr,
@@ -321,20 +367,35 @@ int main(int argc, char** argv)
         }
     });
 
-    // ---- stage 4: writer, in input order (this thread)
+    // ---- stage 4: writer, in input order (this thread).  Records go out with writev straight from the chunk text
+    // (headers, raw sequences) and the pinned canonical buffer: no formatting copy.
     std::vector<std::string> ids;                     // uniq --table: id of every kept record ...
     std::vector<uint64_t> kept_slot;                  // ... found through global index -> slot in ids
     bool table_header = false;
     std::string line;
-    std::vector<char> obuf;
+    std::vector<struct iovec> iov;
+    static const char GT = '>', NL = '\n';
+    if (fflush(out.f) != 0) die("failed to write output");
+    const int ofd = fileno(out.f);
+    auto flush_iov = [&] {
+        size_t i = 0;
+        while (i < iov.size()) {
+            const int cnt = (int)(iov.size() - i < 1024 ? iov.size() - i : 1024);
+            ssize_t w = writev(ofd, iov.data() + i, cnt);
+            if (w < 0) { if (errno == EINTR) continue; die("failed to write output"); }
+            while (w > 0 && i < iov.size()) {          // partial write: advance inside the vector
+                if ((size_t)w >= iov[i].iov_len) { w -= (ssize_t)iov[i].iov_len; ++i; }
+                else { iov[i].iov_base = (char*)iov[i].iov_base + w; iov[i].iov_len -= (size_t)w; w = 0; }
+            }
+        }
+        iov.clear();
+    };
     for (long seq = 0; P.wait(seq, COMPUTED); ++seq) {
         Slot& s = P.slot[seq % Pipeline::K];
         const ckhost::Batch& b = s.batch;
-        const uint8_t* text = s.text.data();
+        const uint8_t* text = s.text;
         const uint64_t n = b.n();
         if (uniq && table) kept_slot.resize(s.base + n, ~0ull);
-        obuf.clear();
-        obuf.reserve(s.len + 2 * n + 64);
         for (uint64_t i = 0; i < n; ++i) {
             const ckhost::Span h = b.head[i];
             if (uniq) {
@@ -355,14 +416,15 @@ int main(int argc, char** argv)
                 }
                 if (!keep) continue;
             }
-            obuf.push_back('>');                                               // src/canonicalize.rs:33-37, src/uniq.rs:50-61
-            obuf.insert(obuf.end(), text + h.off, text + h.off + h.len);
-            obuf.push_back('\n');
-            if (want_bytes) obuf.insert(obuf.end(), s.canon.data() + b.offsets[i], s.canon.data() + b.offsets[i + 1]);
-            else obuf.insert(obuf.end(), text + b.raw[i].off, text + b.raw[i].off + b.raw[i].len);
-            obuf.push_back('\n');
+            // ">" head "\n" sequence "\n"  (src/canonicalize.rs:33-37, src/uniq.rs:50-61)
+            iov.push_back({ (void*)&GT, 1 });
+            if (h.len) iov.push_back({ (void*)(text + h.off), h.len });
+            iov.push_back({ (void*)&NL, 1 });
+            if (want_bytes) { if (b.offsets[i + 1] > b.offsets[i]) iov.push_back({ (void*)(s.canon.data() + b.offsets[i]), (size_t)(b.offsets[i + 1] - b.offsets[i]) }); }
+            else if (b.raw[i].len) iov.push_back({ (void*)(text + b.raw[i].off), b.raw[i].len });
+            iov.push_back({ (void*)&NL, 1 });
         }
-        if (!obuf.empty() && fwrite(obuf.data(), 1, obuf.size(), out.f) != obuf.size()) die("failed to write output");
+        flush_iov();
         P.set(seq, FREE);
     }
     reader.join();
@@ -372,6 +434,7 @@ int main(int argc, char** argv)
     if (table) fclose(table);
     if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
     else if (in.f != stdin) fclose(in.f);
+    for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }   // pinned memory goes before the ctx
     circkit_ctx_destroy(ctx);
     return 0;
 }

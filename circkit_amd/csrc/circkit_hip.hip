@@ -506,6 +506,17 @@ int circkit_canonicalize_batch(circkit_ctx* c, const uint8_t* bytes, const uint6
     return host_batch(c, bytes, offsets, n, out, idx, strand, hash, 0);
 }
 
+void* circkit_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void circkit_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 static int check_ascii(circkit_ctx* c, const uint8_t* s, size_t n)
 {
     if (n && !s) return fail(c, CIRCKIT_ERR_INVALID_ARG, "s is NULL");

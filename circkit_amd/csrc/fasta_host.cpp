@@ -1,11 +1,30 @@
 // fasta_host.cpp -- see fasta_host.h.  Host logic only.
 #include "fasta_host.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/circkit.h"
 
 namespace ckhost {
+
+ByteBuf::~ByteBuf()
+{
+    if (p) { if (release) release(p); else free(p); }
+}
+
+void ByteBuf::reserve(size_t n)
+{
+    if (n <= cap) return;
+    size_t c = cap ? cap : 4096;
+    while (c < n) c += c / 2 + 4096;
+    uint8_t* q = (uint8_t*)(alloc ? alloc(c) : malloc(c));
+    if (!q) abort();
+    if (len) memcpy(q, p, len);
+    if (p) { if (release) release(p); else free(p); }
+    p = q;
+    cap = c;
+}
 
 const uint8_t* normalize_lut()
 {
@@ -52,6 +71,9 @@ bool parse_chunk(const uint8_t* text, size_t n, bool first_chunk, bool final_chu
         }
     }
     const uint8_t* lut = normalize_lut();
+    out.bytes.reserve(limit - pos + 64);        // normalized never exceeds raw: one allocation, no growth below
+    uint8_t* const payload = out.bytes.data();
+    size_t plen = 0;
     out.offsets.push_back(0);
     while (pos < limit) {
         // header line
@@ -75,20 +97,19 @@ bool parse_chunk(const uint8_t* text, size_t n, bool first_chunk, bool final_chu
         if (rlen && text[s0 + rlen - 1] == '\r') --rlen;
         out.raw.push_back(Span{ s0, rlen });
         // normalize while packing
-        const size_t base = out.bytes.size();
-        out.bytes.resize(base + rlen);
-        uint8_t* dst = out.bytes.data() + base;
+        uint8_t* dst = payload + plen;
         size_t m = 0;
         for (size_t k = 0; k < rlen; ++k) {
             const uint8_t o = lut[text[s0 + k]];
             dst[m] = o;
             m += (o != 0);
         }
-        out.bytes.resize(base + m);
-        out.offsets.push_back(out.bytes.size());
+        plen += m;
+        out.offsets.push_back(plen);
         pos = next;
     }
-    out.bytes.resize(out.bytes.size() + 64, 0);
+    memset(payload + plen, 0, 64);
+    out.bytes.len = plen + 64;
     if (consumed) *consumed = limit;
     return true;
 }

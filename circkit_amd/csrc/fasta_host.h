@@ -13,15 +13,32 @@ namespace ckhost {
 
 struct Span { size_t off, len; };
 
+// Growable byte buffer with a pluggable allocator, so the packer can write the CSR payload straight into
+// pinned host memory (circkit_host_alloc) and the H2D copy is a plain DMA.
+struct ByteBuf {
+    uint8_t* p = nullptr;
+    size_t len = 0, cap = 0;
+    void* (*alloc)(size_t) = nullptr;       // nullptr = malloc / free
+    void (*release)(void*) = nullptr;
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    ~ByteBuf();
+    void reserve(size_t n);                 // keeps the first `len` bytes
+    uint8_t* data() { return p; }
+    const uint8_t* data() const { return p; }
+    size_t size() const { return len; }
+};
+
 // One parsed chunk of FASTA text: per record the header span, the raw sequence span (interior line breaks kept,
 // final line break dropped -- what seq_io's RefRecord::seq() returns) and the normalized bytes in CSR layout.
 struct Batch {
     const uint8_t* text = nullptr;          // the chunk the spans point into (owned by the caller)
     std::vector<Span> head, raw;
-    std::vector<uint8_t> bytes;             // normalized payload, + 64 bytes of zero padding
+    ByteBuf bytes;                          // normalized payload, + 64 bytes of zero padding
     std::vector<uint64_t> offsets;          // n_records + 1
     size_t n() const { return head.size(); }
-    void clear() { head.clear(); raw.clear(); bytes.clear(); offsets.clear(); }
+    void clear() { head.clear(); raw.clear(); bytes.len = 0; offsets.clear(); }
 };
 
 // needletail normalize LUT: 0 = drop (space, \t, \r, \n), otherwise the output byte.

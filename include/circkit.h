@@ -94,6 +94,11 @@ int circkit_canonicalize_batch(circkit_ctx* ctx, const uint8_t* bytes, const uin
                                uint64_t n_records, uint8_t* out_bytes, uint32_t* out_index,
                                uint8_t* out_strand, uint64_t* out_xxh3);
 
+/* Page-locked host memory for batch buffers: with bytes / out_bytes allocated here the host-buffer entry points
+ * copy by plain DMA instead of through the runtime's pageable staging.  Needs a HIP device (NULL otherwise). */
+void* circkit_host_alloc(size_t bytes);
+void circkit_host_free(void* p);
+
 /* ---- single record: 1:1 mirror of the lib crate (lib/src/lib.rs:1,3) ------------------------------ */
 /* pub fn lmsr_index(x: &[u8]) -> usize            lib/src/canonicalize.rs:5  */
 int circkit_lmsr_index(circkit_ctx* ctx, const uint8_t* s, size_t n, size_t* out_index);
