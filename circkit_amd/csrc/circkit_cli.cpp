@@ -20,6 +20,8 @@
 #include <sys/uio.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <new>
 #include <mutex>
@@ -190,6 +192,18 @@ void check(circkit_ctx* ctx, int rc)
     if (rc != CIRCKIT_OK) die(std::string("GPU path failed: ") + circkit_last_error(ctx));
 }
 
+// CIRCKIT_CLI_TIMING=1: busy seconds per pipeline stage on stderr (stages overlap; wall is what counts)
+struct Busy {
+    std::atomic<long> ns{ 0 };
+    struct Scope {
+        Busy& b; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        explicit Scope(Busy& bb) : b(bb) {}
+        ~Scope() { b.ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    };
+    double s() const { return ns.load() * 1e-9; }
+};
+Busy g_read, g_parse, g_gpu, g_write;
+
 // ---- the pipeline ------------------------------------------------------------------------------------------
 // reader -> parser pool -> GPU -> writer over a ring of chunk slots.  Mirrors seq_io's parallel_fasta shape
 // (one reader, `--threads` workers, results consumed in input order: src/canonicalize.rs:17-45) with the worker
@@ -284,6 +298,7 @@ int main(int argc, char** argv)
             size_t pos = 0;
             do {
                 P.wait(seq, FREE);
+                Busy::Scope tb(g_read);
                 Slot& s = P.slot[seq % Pipeline::K];
                 size_t want = Pipeline::CHUNK, cut = 0;
                 for (;;) {
@@ -302,6 +317,7 @@ int main(int argc, char** argv)
             bool eof = false;
             while (!eof || !carry.empty()) {
                 P.wait(seq, FREE);
+                Busy::Scope tb(g_read);
                 Slot& s = P.slot[seq % Pipeline::K];
                 size_t have = carry.size();
                 if (s.own.size() < have + Pipeline::CHUNK) s.own.resize(have + Pipeline::CHUNK);
@@ -338,6 +354,7 @@ int main(int argc, char** argv)
                 long seq;
                 { std::lock_guard<std::mutex> g(P.m); seq = P.next_parse++; }
                 if (!P.wait(seq, READ)) return;
+                Busy::Scope tb(g_parse);
                 Slot& s = P.slot[seq % Pipeline::K];
                 std::string err;
                 size_t consumed = 0;
@@ -350,6 +367,7 @@ int main(int argc, char** argv)
     std::thread gpu([&] {
         uint64_t base = 0;
         for (long seq = 0; P.wait(seq, PARSED); ++seq) {
+            Busy::Scope tb(g_gpu);
             Slot& s = P.slot[seq % Pipeline::K];
             const uint64_t n = s.batch.n();
             s.base = base;
@@ -391,6 +409,7 @@ int main(int argc, char** argv)
         iov.clear();
     };
     for (long seq = 0; P.wait(seq, COMPUTED); ++seq) {
+        Busy::Scope tb(g_write);
         Slot& s = P.slot[seq % Pipeline::K];
         const ckhost::Batch& b = s.batch;
         const uint8_t* text = s.text;
@@ -430,6 +449,9 @@ int main(int argc, char** argv)
     reader.join();
     for (auto& t : parsers) t.join();
     gpu.join();
+    if (getenv("CIRCKIT_CLI_TIMING"))
+        fprintf(stderr, "busy: read %.3f s  parse+pack %.3f (sum over %d threads)  gpu %.3f  write %.3f\n", g_read.s(), g_parse.s(),
+                n_parsers, g_gpu.s(), g_write.s());
     close_output(out);
     if (table) fclose(table);
     if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
