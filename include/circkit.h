@@ -87,9 +87,11 @@ int circkit_xxh3_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const ui
 int circkit_ctx_batch_status(circkit_ctx* ctx, uint32_t* n_unprocessed);
 
 /* ---- batch, host buffers ---------------------------------------------------------------------- */
-/* Same contract with HOST pointers: copies the batch to the device (pinned staging, chunked, copy
- * overlapped with compute), runs circkit_canonicalize_batch_device, copies the requested outputs back
- * and returns when they are complete.  offsets[0] must be 0. */
+/* Same contract with HOST pointers: copies the batch into ctx-owned device buffers (grow-only), runs
+ * circkit_canonicalize_batch_device, copies the requested outputs back and returns when they are complete.
+ * Buffers from circkit_host_alloc (page-locked) are copied by DMA; pageable memory goes through the runtime's
+ * staging.  Streaming hosts overlap this call with their own parsing / writing (see circkit_cli.cpp).
+ * offsets[0] must be 0. */
 int circkit_canonicalize_batch(circkit_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets,
                                uint64_t n_records, uint8_t* out_bytes, uint32_t* out_index,
                                uint8_t* out_strand, uint64_t* out_xxh3);

@@ -286,3 +286,52 @@ def test_uniq_repeated_fixture(ctx, O):
     got = ctx.canonicalize_batch(data, offs, want_xxh3=True)
     assert len(set(got["xxh3"].tolist())) == 1
     assert got["bytes"][:8].tobytes() == b"AAAAAAAT"
+
+
+def test_lmsr_and_xxh3_device_batches(ctx, O):
+    """circkit_lmsr_batch_device (forward strand only, lib/src/canonicalize.rs:41-47) and circkit_xxh3_batch_device."""
+    import torch
+    from tests import seqsets
+    seqs = seqsets.random_mixed(61, 300, 1, 1500) + seqsets.random_mixed(62, 100, 1, 600, b"ACGTN") + [b"banana", b"TAA", b""]
+    data, offs = seqsets.pack(seqs)
+    n = len(seqs)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+    d_bytes[:len(data)] = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_out = torch.zeros_like(d_bytes)
+    d_idx = torch.empty(n, dtype=torch.int32, device=dev)
+    d_hash = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.lmsr_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_index=d_idx)
+    ctx.xxh3_batch_device(d_out, d_off, n, d_hash)
+    torch.cuda.synchronize()
+    out, idx, hs = d_out.cpu().numpy(), d_idx.cpu().numpy(), d_hash.cpu().numpy().astype(np.uint64)
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == O.lmsr(s), (i, s[:60])
+        assert int(hs[i]) == O.xxh3_64(O.lmsr(s))
+        if s:
+            assert int(idx[i]) == O.lmsr_index(s)
+    ctx.use_own_stream()
+
+
+def test_pinned_host_buffers(ctx, O):
+    """circkit_host_alloc: page-locked batch buffers through the host API."""
+    import ctypes
+    import circkit_amd
+    from tests import seqsets
+    lib = circkit_amd.load_library()
+    seqs = seqsets.random_mixed(63, 200, 900, 1100)
+    data, offs = seqsets.pack(seqs)
+    n, total = len(seqs), len(data)
+    pin_in, pin_out = lib.circkit_host_alloc(total + 64), lib.circkit_host_alloc(total + 64)
+    assert pin_in and pin_out
+    ctypes.memmove(pin_in, data.ctypes.data, total)
+    rc = lib.circkit_canonicalize_batch(ctx._h, pin_in, offs.ctypes.data, n, pin_out, None, None, None)
+    assert rc == 0
+    got = np.ctypeslib.as_array(ctypes.cast(pin_out, ctypes.POINTER(ctypes.c_uint8)), shape=(total,)).copy()
+    exp, _ = O.canonicalize_batch(data, offs, True, False, threads=4)
+    assert np.array_equal(got, exp)
+    lib.circkit_host_free(pin_in)
+    lib.circkit_host_free(pin_out)
