@@ -170,6 +170,11 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
 // record must go to the general kernel: a byte outside ACGT, or a minimal key that is not unique.
 // Single exit: the rare failures are folded into one flag instead of early returns, which keeps the
 // scalar unit's branch / mask bookkeeping off the hot path.
+// OVERLAP_TAIL: lanes >= n/16 were loaded with the record's LAST 16 bytes (canon_fast's own DMA) and the tail symbols
+// must be shifted up; otherwise lane t holds bytes [16t, 16t+16) and whatever follows the record (canon_stream's
+// staged image): the tail word's trailing symbols are replaced by the extension below and only lanes < ceil(n/16) are
+// checked for validity.
+template <bool OVERLAP_TAIL = true>
 CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
                          u32x4 bytes)
 {
@@ -177,7 +182,8 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHash
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
     uint64_t bad;
     uint32_t F = fast_pack(bytes, bad);
-    F <<= t >= nwf ? ((16 - r) & 15) * 2 : 0;
+    if (OVERLAP_TAIL) F <<= t >= nwf ? ((16 - r) & 15) * 2 : 0;
+    else bad &= nwv >= 64 ? ~0ull : ((1ull << nwv) - 1);
     // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
     {
         const uint32_t A = shfl(F, t - nwv), B = shfl(F, t - nwv + 1);

@@ -11,11 +11,15 @@
 #include "../../include/circkit.h"
 #include "canon_core.h"
 #include "canon_fast.h"
+#include "canon_stream.h"
 #ifndef CK_FAST_NB
 #define CK_FAST_NB 3
 #endif
 #ifndef CK_FAST_WPE
 #define CK_FAST_WPE 1     // min waves per SIMD the streaming kernel is compiled for
+#endif
+#ifndef CK_STREAM_STAGED
+#define CK_STREAM_STAGED 1   // 1: canon_stream.h (workgroup-staged input); 0: canon_fast.h's per-wave prefetch
 #endif
 #ifndef CK_FAST_BPC
 #define CK_FAST_BPC 64    // workgroups launched per CU (6 resident; the rest queue: finer dynamic balance, measured best of 8..128)
@@ -56,6 +60,21 @@ __global__ __launch_bounds__(256, CK_FAST_WPE) void canon_fast_kernel(ck::CanonA
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + wib);
     ck::canon_fast_wave_loop<FAST_NB>(a, lut, lds + wib * 256 * FAST_NB, blk_count, blockIdx.x, wave, gridDim.x * 4);
+    __syncthreads();
+    if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
+}
+
+// The streaming kernel with workgroup-staged input (canon_stream.h): a ring of three 8 KiB images of 8-record groups
+// per workgroup, the decode table and the deferral counter.
+__global__ __launch_bounds__(256, CK_FAST_WPE) void canon_stream_kernel(ck::CanonArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[ck::STREAM_NBUF * ck::STREAM_BUF_DW + 256 + 4];
+    uint32_t* lut = lds + ck::STREAM_NBUF * ck::STREAM_BUF_DW;
+    uint32_t* blk_count = lut + 256;
+    ck::fast_lut_init(lut, threadIdx.x, 256);
+    if (threadIdx.x == 0) *blk_count = 0;
+    __syncthreads();
+    ck::canon_stream_wave_loop(a, lut, lds, blk_count, blockIdx.x, gridDim.x);
     __syncthreads();
     if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
 }
@@ -264,9 +283,10 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs to
     // workgroup b); the one-wave tiers B, C take 4 segments per workgroup each; tier D is the end of the line
-    const uint64_t blocks = (n + 3) / 4;
+    const uint64_t per_step = CK_STREAM_STAGED ? ck::STREAM_GROUP : 4;     // records a workgroup takes per iteration
+    const uint64_t blocks = (n + per_step - 1) / per_step;
     const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
-    const uint32_t cap = (uint32_t)(4 * ((n + 4ull * G - 1) / (4ull * G)));       // records one workgroup can see
+    const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
     int rc = ensure_lists(c, (uint64_t)G * cap + 64ull * cap, G);
     if (rc) return rc;
     if (d_hash && !d_out) {
@@ -301,7 +321,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
-    hipLaunchKernelGGL(canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(CK_STREAM_STAGED ? canon_stream_kernel : canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
     unsigned nseg = G;              // segments / capacity of the list the next tier consumes
     uint32_t seg_cap = cap;
     for (int t = 0; t < N_TIERS; ++t) {

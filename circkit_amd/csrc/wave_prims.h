@@ -22,6 +22,8 @@
 namespace ck {
 
 CK_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+CK_DEV uint32_t wave_in_block() { return (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+CK_DEV void block_barrier() { __syncthreads(); }
 CK_DEV uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 CK_DEV uint32_t shfl(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
 CK_DEV uint32_t readlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
@@ -197,6 +199,15 @@ CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b)
     b = ((uint64_t)r.w << 32) | r.z;
 }
 
+// two independent u64 (e.g. the first and last offset of a record group), one wait
+CK_DEV void sload_2u64(const uint64_t* p0, const uint64_t* p1, uint64_t& a, uint64_t& b)
+{
+    uint64_t x, y;
+    asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(x), "=&s"(y) : "s"(p0), "s"(p1) : "memory");
+    a = x; b = y;
+}
+
 }  // namespace ck
 
 #else
@@ -211,10 +222,14 @@ namespace ck {
 
 namespace emu {
 uint32_t cur_lane();
+uint32_t cur_wave();
 void gather(uint64_t v, uint64_t out[64]);   // collective all-gather over the 64 lanes of the wave
+void block_barrier();                        // rendezvous of every fiber of the workgroup
 }
 
 CK_DEV uint32_t lane_id() { return emu::cur_lane(); }
+CK_DEV uint32_t wave_in_block() { return emu::cur_wave(); }
+CK_DEV void block_barrier() { emu::block_barrier(); }
 CK_DEV uint64_t ballot(bool p)
 {
     uint64_t all[64]; emu::gather(p ? 1 : 0, all);
@@ -308,6 +323,7 @@ CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc) { memcpy((uint8
 template <int N>
 CK_DEV void vmem_wait() {}
 CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b) { a = p[0]; b = p[1]; }
+CK_DEV void sload_2u64(const uint64_t* p0, const uint64_t* p1, uint64_t& a, uint64_t& b) { a = *p0; b = *p1; }
 
 }  // namespace ck
 #endif

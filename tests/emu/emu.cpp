@@ -10,72 +10,95 @@
 #include "../../circkit_amd/csrc/wave_prims.h"
 
 namespace ck { namespace emu {
-struct WaveState {
-    ucontext_t main_ctx, ctx[64];
-    std::vector<char> stacks;
-    int cur = 0;
+// A workgroup = NW waves of 64 fibers.  Wave-level collectives rendezvous the 64 fibers of one wave; block_barrier()
+// rendezvous all fibers of the workgroup.  run_wave() is the 1-wave special case.
+constexpr int MAXW = 4;
+struct WaveSync {
     uint64_t buf[2][64];
-    int cnt[2] = {0, 0};
-    uint32_t complete[2] = {0xFFFFFFFFu, 0xFFFFFFFEu};
-    uint32_t gen[64];
-    bool done[64];
+    int cnt[2];
+    uint32_t complete[2];
+};
+struct BlockState {
+    ucontext_t main_ctx, ctx[64 * MAXW];
+    std::vector<char> stacks;
+    int nfib = 64, cur = 0;
+    WaveSync ws[MAXW];
+    uint32_t gen[64 * MAXW];
+    bool done[64 * MAXW];
+    int bar_cnt[2];
+    uint32_t bar_complete[2], bar_gen[64 * MAXW];
     void (*body)(void*) = nullptr;
     void* arg = nullptr;
 };
-static WaveState* W = nullptr;
+static BlockState* B = nullptr;
 
-uint32_t cur_lane() { return (uint32_t)W->cur; }
+uint32_t cur_lane() { return (uint32_t)(B->cur & 63); }
+uint32_t cur_wave() { return (uint32_t)(B->cur >> 6); }
 
-static void yield_next()
+static void yield_next(const char* what)
 {
-    int from = W->cur, nx = from;
-    for (int t = 0; t < 64; ++t) {
-        nx = (nx + 1) & 63;
-        if (!W->done[nx]) break;
+    int from = B->cur, nx = from;
+    for (int t = 0; t < B->nfib; ++t) {
+        nx = (nx + 1) % B->nfib;
+        if (!B->done[nx]) break;
     }
-    if (nx == from || W->done[nx]) {
-        fprintf(stderr, "emu: wave deadlock -- lane %d waits in a collective the other lanes never reach\n", from);
+    if (nx == from || B->done[nx]) {
+        fprintf(stderr, "emu: deadlock -- fiber %d (wave %d lane %d) waits in a %s the others never reach\n", from, from >> 6,
+                from & 63, what);
         abort();
     }
-    W->cur = nx;
-    swapcontext(&W->ctx[from], &W->ctx[nx]);
+    B->cur = nx;
+    swapcontext(&B->ctx[from], &B->ctx[nx]);
 }
 
 void gather(uint64_t v, uint64_t out[64])
 {
-    const int l = W->cur;
-    const uint32_t g = W->gen[l]++;
+    const int f = B->cur, l = f & 63;
+    WaveSync& w = B->ws[f >> 6];
+    const uint32_t g = B->gen[f]++;
     const int s = g & 1;
-    W->buf[s][l] = v;
-    if (++W->cnt[s] == 64) { W->complete[s] = g; W->cnt[s] = 0; }
-    while (W->complete[s] != g) yield_next();
-    for (int i = 0; i < 64; ++i) out[i] = W->buf[s][i];
+    w.buf[s][l] = v;
+    if (++w.cnt[s] == 64) { w.complete[s] = g; w.cnt[s] = 0; }
+    while (w.complete[s] != g) yield_next("wave collective");
+    for (int i = 0; i < 64; ++i) out[i] = w.buf[s][i];
+}
+
+void block_barrier()
+{
+    const int f = B->cur;
+    const uint32_t g = B->bar_gen[f]++;
+    const int s = g & 1;
+    if (++B->bar_cnt[s] == B->nfib) { B->bar_complete[s] = g; B->bar_cnt[s] = 0; }
+    while (B->bar_complete[s] != g) yield_next("workgroup barrier");
 }
 
 static void trampoline()
 {
-    const int l = W->cur;
-    W->body(W->arg);
-    W->done[l] = true;
-    // hand over to the next unfinished lane, or back to main when all are done
-    for (int t = 1; t <= 64; ++t) {
-        int nx = (l + t) & 63;
-        if (!W->done[nx]) { W->cur = nx; setcontext(&W->ctx[nx]); }
+    const int f = B->cur;
+    B->body(B->arg);
+    B->done[f] = true;
+    for (int t = 1; t <= B->nfib; ++t) {        // hand over to the next unfinished fiber, or back to main
+        int nx = (f + t) % B->nfib;
+        if (!B->done[nx]) { B->cur = nx; setcontext(&B->ctx[nx]); }
     }
-    setcontext(&W->main_ctx);
+    setcontext(&B->main_ctx);
 }
 
-void run_wave(void (*body)(void*), void* arg)
+void run_block(void (*body)(void*), void* arg, int nwaves)
 {
-    static WaveState st;
-    W = &st;
+    static BlockState st;
+    B = &st;
     const size_t STK = 256 * 1024;
-    if (st.stacks.empty()) st.stacks.resize(64 * STK);
-    st.body = body; st.arg = arg;
-    st.cnt[0] = st.cnt[1] = 0;
-    st.complete[0] = 0xFFFFFFFFu; st.complete[1] = 0xFFFFFFFEu;
-    for (int i = 0; i < 64; ++i) {
-        st.gen[i] = 0; st.done[i] = false;
+    if (st.stacks.empty()) st.stacks.resize(64 * MAXW * STK);
+    st.body = body; st.arg = arg; st.nfib = 64 * nwaves;
+    for (int w = 0; w < MAXW; ++w) {
+        st.ws[w].cnt[0] = st.ws[w].cnt[1] = 0;
+        st.ws[w].complete[0] = 0xFFFFFFFFu; st.ws[w].complete[1] = 0xFFFFFFFEu;
+    }
+    st.bar_cnt[0] = st.bar_cnt[1] = 0;
+    st.bar_complete[0] = 0xFFFFFFFFu; st.bar_complete[1] = 0xFFFFFFFEu;
+    for (int i = 0; i < st.nfib; ++i) {
+        st.gen[i] = 0; st.bar_gen[i] = 0; st.done[i] = false;
         getcontext(&st.ctx[i]);
         st.ctx[i].uc_stack.ss_sp = st.stacks.data() + i * STK;
         st.ctx[i].uc_stack.ss_size = STK;
@@ -84,13 +107,16 @@ void run_wave(void (*body)(void*), void* arg)
     }
     st.cur = 0;
     swapcontext(&st.main_ctx, &st.ctx[0]);
-    for (int i = 0; i < 64; ++i)
-        if (!st.done[i]) { fprintf(stderr, "emu: lane %d did not finish\n", i); abort(); }
+    for (int i = 0; i < st.nfib; ++i)
+        if (!st.done[i]) { fprintf(stderr, "emu: fiber %d did not finish\n", i); abort(); }
 }
+
+void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 }}  // namespace ck::emu
 
 #include "../../circkit_amd/csrc/canon_core.h"
 #include "../../circkit_amd/csrc/canon_fast.h"
+#include "../../circkit_amd/csrc/canon_stream.h"
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
@@ -104,6 +130,11 @@ void fast_body(void* p)
 {
     Launch* L = (Launch*)p;
     ck::canon_fast_wave_loop<4>(L->a, L->lut, L->lds, L->blk_count, L->block, L->block * 4 + L->wib, L->nblocks * 4);
+}
+void stream_body(void* p)       // one fiber of a 4-wave workgroup
+{
+    Launch* L = (Launch*)p;
+    ck::canon_stream_wave_loop(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
 }
 }
 
@@ -121,7 +152,7 @@ void hash_body(void* q)
 extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                       uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
                                       uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
-                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast, uint32_t* n_fused_hash)
+                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast, uint32_t* n_fused_hash, int staged)
 {
     uint8_t comp[256];
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
@@ -129,7 +160,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
     const uint32_t G = (n_waves + 3) / 4;
     const uint32_t cap = (uint32_t)(4 * ((n_records + 4ull * G - 1) / (4ull * G))) + 4;
-    std::vector<uint32_t> lds((slice_dw > 1024 ? slice_dw : 1024) + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    std::vector<uint32_t> lds((slice_dw > 3 * ck::STREAM_BUF_DW ? slice_dw : 3 * ck::STREAM_BUF_DW) + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[256];
     ck::fast_lut_init(lut, 0, 1);
@@ -146,7 +177,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;
         L.block = b; L.blk_count = &blk;
-        for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(fast_body, &L); }
+        if (staged) ck::emu::run_block(stream_body, &L, 4);
+        else for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(fast_body, &L); }
         cnt_f[b] = blk; total_f += blk;
     }
     if (n_fast) *n_fast = (uint32_t)n_records - total_f;

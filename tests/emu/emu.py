@@ -23,12 +23,12 @@ last_fast_count = 0
 last_fused_hash_count = 0
 
 
-def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0):
+def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=True):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.emu_canonicalize_batch.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4 + \
-            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
@@ -43,7 +43,7 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     nfused = ctypes.c_uint32(0)
     st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data, idx.ctypes.data,
                                      strand.ctypes.data, hs.ctypes.data if want_hash else None,
-                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused))
+                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged))
     global last_fast_count, last_fused_hash_count
     last_fast_count = nfast.value
     last_fused_hash_count = nfused.value

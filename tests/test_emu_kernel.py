@@ -86,10 +86,13 @@ def test_streaming_kernel_takes_the_headline_records():
     """Pure-ACGT 1 kb records must be handled by the register-resident streaming kernel, not the LDS tier."""
     seqs = seqsets.random_mixed(35, 64, 1000, 1000)
     data, offs = seqsets.pack(seqs)
-    emu.canonicalize_batch(data, offs)
+    emu.canonicalize_batch(data, offs, staged=False)
     assert emu.last_fast_count == len(seqs)
-    emu.canonicalize_batch(*seqsets.pack([b"ACGTN" * 200, b"A" * 500, b"ACGT" * 10, b"ACGT" * 300]))
-    assert emu.last_fast_count == 0     # N, repeats, too short, too long -> general kernel
+    emu.canonicalize_batch(data, offs, staged=True)
+    assert emu.last_fast_count == len(seqs) - 8     # the batch's last group of 8 is left to the general kernel
+    for staged in (False, True):
+        emu.canonicalize_batch(*seqsets.pack([b"ACGTN" * 200, b"A" * 500, b"ACGT" * 10, b"ACGT" * 300] * 4), staged=staged)
+        assert emu.last_fast_count == 0     # N, repeats, too short, too long -> general kernel
 
 
 def test_fused_xxh3_matches_oracle():
