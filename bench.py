@@ -185,7 +185,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(N, L) if args.workload == "canonicalize" else None,
-                         "kernel": "canon_fast_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+                         "kernel": "canon_stream_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
         }
         if args.workload == "uniq":
             result["unique_records"] = int((d_fs == torch.arange(rank * N, rank * N + N, device=dev)).sum().item())

@@ -64,23 +64,27 @@ CK_DEV u32x4 fast_fetch(const uint32_t* buf)
     return u32x4{ p[0], p[1], p[2], p[3] };
 }
 
-// 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); `bad` = wave mask of lanes holding a byte
-// that is not A/C/G/T.  Validity = the check LUT reproduces the dword; four ballots keep it at one v_cmp_ne
-// per dword with the ORs on the scalar unit.
-CK_DEV uint32_t fast_pack(u32x4 v, uint64_t& bad)
+// 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); `invalid` = this lane holds a byte that is
+// not A/C/G/T.  Per dword: shift+mask to a 3-bit selector, v_perm for the check byte and for the code, one
+// v_bitop3 to accumulate the mismatch, one v_dot4_u32_u8 (weights 64,16,4,1) to gather the four codes into a byte.
+CK_DEV uint32_t fast_pack(u32x4 v, bool& invalid)
 {
     const uint32_t d[4] = { v.x, v.y, v.z, v.w };
-    uint32_t u[4];
-    bad = 0;
+    uint32_t u[4], miss = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t sel = (d[k] >> 1) & HASH_MASK;
-        bad |= ballot(perm(0u, CHK2_LO, sel) != d[k]);
+        miss |= perm(0u, CHK2_LO, sel) ^ d[k];
+#ifdef CK_DBG_NO_DOT4
         const uint32_t code = perm(0u, 0x02030100u, sel);
-        const uint32_t t = code | (code << 10);
-        u[k] = t | (t << 20);
+        const uint32_t tt = code | (code << 10);
+        u[k] = (tt | (tt << 20)) >> 24;
+#else
+        u[k] = udot4(perm(0u, 0x02030100u, sel), 0x01041040u, 0u);
+#endif
     }
-    return perm(u[0], u[1], 0x07030c0cu) | perm(u[2], u[3], 0x0c0c0703u);
+    invalid = miss != 0;
+    return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
 }
 
 // 256-entry LDS table: packed byte (4 symbols, first in the top bits) -> its 4 ASCII bytes.  Replaces ~6 VALU
@@ -166,24 +170,18 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
     return ((uint64_t)readlane((uint32_t)(h >> 32), 15) << 32) | readlane((uint32_t)h, 15);
 }
 
-// Canonicalizes one eligible record held as 16 bytes per lane; returns false (nothing written) when the
-// record must go to the general kernel: a byte outside ACGT, or a minimal key that is not unique.
-// Single exit: the rare failures are folded into one flag instead of early returns, which keeps the
-// scalar unit's branch / mask bookkeeping off the hot path.
-// OVERLAP_TAIL: lanes >= n/16 were loaded with the record's LAST 16 bytes (canon_fast's own DMA) and the tail symbols
-// must be shifted up; otherwise lane t holds bytes [16t, 16t+16) and whatever follows the record (canon_stream's
-// staged image): the tail word's trailing symbols are replaced by the extension below and only lanes < ceil(n/16) are
-// checked for validity.
-template <bool OVERLAP_TAIL = true>
-CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
-                         u32x4 bytes)
+// Canonicalizes one eligible record held as packed words: lane t = symbols [16t, 16t+16) (whatever follows the
+// record in the tail word is replaced by the periodic extension), bad = wave mask of lanes holding a byte outside
+// ACGT.  Returns false (nothing written) when the record must go to the general kernel: an invalid byte, a minimal
+// key that is not unique, or equal minimal keys on the two strands.  Single exit: the rare failures are folded into
+// one flag instead of early returns, which keeps the scalar unit's branch / mask bookkeeping off the hot path.
+// HASH = false compiles the fused XXH3 out.
+template <bool HASH>
+CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
+                       uint32_t F, uint64_t bad)
 {
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
-    uint64_t bad;
-    uint32_t F = fast_pack(bytes, bad);
-    if (OVERLAP_TAIL) F <<= t >= nwf ? ((16 - r) & 15) * 2 : 0;
-    else bad &= nwv >= 64 ? ~0ull : ((1ull << nwv) - 1);
     // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
     {
         const uint32_t A = shfl(F, t - nwv), B = shfl(F, t - nwv + 1);
@@ -209,30 +207,24 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHash
     mC = valid ? mC : ~0u;
     uint32_t MF, MC;
     wave_min2_u32(mF, mC, MF, MC);
+    // lexicographic select (lib/src/canonicalize.rs:58-62).  The minimal keys ARE the first 16 symbols of the two
+    // minimal rotations, so they decide unless equal (reverse-complement palindromes: left to the general kernel),
+    // and only the winning strand's rotation has to be located -- unless the rotation index is asked for, which
+    // for the reverse strand is counted from the forward strand's minimal rotation.
+    const bool fwd = fwd_only || MF <= MC;
+    const bool tie = !fwd_only && MF == MC;
     const uint32_t shv = 32 - 2 * (t & 15);
-    bool uF, uC;
-    const uint32_t iF = fast2_locate(F, Fn, ballot(mF == MF), MF, n, shv, uF);
-    const uint32_t iC = fast2_locate(C, Cn, ballot(mC == MC), MC, n, shv, uC);
-    if (bad != 0 || !uF || !(uC || fwd_only)) return false;
-    // lexicographic select (lib/src/canonicalize.rs:58-62).  The minimal keys ARE the first 16 symbols of
-    // the two minimal rotations, so they decide unless equal; only then compare the full rotations.
-    bool fwd = fwd_only || MF < MC;
-    if (!fwd_only && MF == MC) {
-        const uint32_t wa = reg_sym_word(F, iF + 16 * t, n), wb = reg_sym_word(C, iC + 16 * t, n);
-        const uint32_t d = valid ? (wa ^ wb) : 0u;
-        const uint64_t bal = ballot(d != 0);
-        if (bal) {
-            const uint32_t l = (uint32_t)ffs64(bal);
-            const uint32_t k = 16 * l + (uint32_t)clz32(readlane(d, l)) / 2;
-            fwd = k < n && readlane(wa, l) < readlane(wb, l);
-        }
-    }
+    const uint32_t E = fwd ? F : C;
+    bool uE, uF = true;
+    const uint32_t idx = fast2_locate(E, fwd ? Fn : Cn, fwd ? ballot(mF == MF) : ballot(mC == MC), fwd ? MF : MC, n, shv, uE);
+    uint32_t iF = idx;
+    if (a.out_index && !fwd) iF = fast2_locate(F, Fn, ballot(mF == MF), MF, n, shv, uF);
+    if (bad != 0 || tie || !uE || !uF) return false;
     {
         // every lane stores a full 16 bytes: the last lane's window is pulled back to end exactly at n, so it
         // overlaps its neighbour's with identical bytes -- one store instruction, no partial-store branches
         const uint32_t o = 16 * t + 16 <= n ? 16 * t : n - 16;
-        const uint32_t E = fwd ? F : C, idx = fwd ? iF : iC;
-        const bool hash = a.out_hash != nullptr && n > 240;             // XXH3's long-input path; shorter: xxh3 pass
+        const bool hash = HASH && a.out_hash != nullptr && n > 240;     // XXH3's long-input path; shorter: xxh3 pass
         const bool store = a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL));
         if (store || hash) {
             const u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
@@ -244,11 +236,22 @@ CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHash
         }
     }
     if (t == 0) {
-        // unique minimum => period n; iC + iF < 2n
-        if (a.out_index) a.out_index[rec] = fwd ? iF : (iC + iF >= n ? iC + iF - n : iC + iF);
+        // unique minimum => period n; idx + iF < 2n
+        if (a.out_index) a.out_index[rec] = fwd ? idx : (idx + iF >= n ? idx + iF - n : idx + iF);
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
     return true;
+}
+
+// canon_fast's own input: 16 bytes per lane at the record's alignment, lanes >= n/16 loaded with the record's LAST
+// 16 bytes (so every load stays inside the record): their tail symbols are shifted up to the top of the word.
+CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
+                         u32x4 bytes)
+{
+    bool invalid;
+    uint32_t F = fast_pack(bytes, invalid);
+    F <<= lane_id() >= (n >> 4) ? ((16 - (n & 15)) & 15) * 2 : 0;
+    return fast_canon<true>(a, lut, hc, rec, off, n, F, ballot(invalid));
 }
 
 // Software-pipelined grid-stride loop of one wave over a ring of NB 1 KiB LDS buffers: while record k is

@@ -14,105 +14,118 @@
 
 namespace ck {
 
-constexpr uint32_t STREAM_GROUP = 8;                     // records per group (two per wave)
-constexpr uint32_t STREAM_SPAN = 8192;                   // bytes of one LDS image: 8 x 1008 + alignment slack fits
-constexpr uint32_t STREAM_BUF_DW = (STREAM_SPAN + 64) / 4;   // + one chunk of read slack for the funnel
-constexpr int STREAM_NBUF = 3;
+// Geometry of one workgroup: WPB waves, two records per wave per group, NBUF images in the LDS ring (NBUF-1 groups in
+// flight).  A group is 2*WPB consecutive records; its image is 1 KiB per record (1008 B at most + the 16 B alignment
+// slack of the span start), so every wave issues exactly two DMA instructions per group.
+template <int WPB_, int NBUF_>
+struct StreamCfg {
+    static constexpr int WPB = WPB_, RPW = 2, NBUF = NBUF_;
+    static constexpr uint32_t GROUP = WPB * RPW;                // records per group
+    static constexpr uint32_t SPAN = GROUP * 1024;              // bytes of one image
+    static constexpr uint32_t BUF_DW = (SPAN + 64) / 4;
+    // ring, then the decode table and the deferral counter: a record's lanes past its end read up to 63 chunks
+    // beyond the image (never used), which for the last buffer lands in the table -- keep it behind the ring
+    static constexpr uint32_t LDS_DW = NBUF * BUF_DW + 256 + 4;
+};
 
 struct StreamGroup {
-    uint64_t base;      // byte offset (into a.bytes) of the image's first byte: span start rounded down to 16
+    uint32_t base_lo;   // low 32 bits of the byte offset (into a.bytes) of the image's first byte
     bool ok;            // staged (else: every record of the group goes to the general kernel)
 };
 
-// Every wave issues exactly two DMA instructions (chunks wave*128 + {0,64} + lane of the image), whatever the group
-// looks like -- the vmcnt bookkeeping of the loop depends on it.  Lanes past the span re-fetch its last chunk;
-// unstaged groups fetch the offsets array (always readable).
-CK_DEV StreamGroup stream_issue(const CanonArgs& a, uint32_t g, uint32_t n_groups, uint32_t* buf)
+// DMA of the group whose first / one-past-last offsets are s, e.  Every wave issues exactly RPW instructions (chunks
+// (wave*RPW + i)*64 + lane of the image), whatever the group looks like -- the vmcnt bookkeeping of the loop depends
+// on it.  Lanes past the span re-fetch its last chunk; unstaged groups fetch the offsets array (always readable).
+template <class C>
+CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, uint64_t e, uint32_t* buf)
 {
-    const uint32_t gg = g < n_groups ? g : n_groups - 1;
-    const uint64_t N = a.n_records, r0 = (uint64_t)gg * STREAM_GROUP, r1 = r0 + STREAM_GROUP < N ? r0 + STREAM_GROUP : N;
-    uint64_t s, e;
-    sload_2u64(a.offsets + r0, a.offsets + r1, s, e);
-    const uint64_t addr = (uint64_t)(uintptr_t)a.bytes + s;
+    const uint32_t mis = ((uint32_t)(uintptr_t)a.bytes + (uint32_t)s) & 15;
+    const uint64_t base = s - mis;
+    const uint64_t nbytes = e - base;
     StreamGroup grp;
-    grp.base = s - (addr & 15);
-    const uint64_t nbytes = e - grp.base;
-    // not staged: the batch's last group (its final chunk would read past the payload), a group whose first chunk
-    // would start before the payload (unaligned d_bytes), empty or oversized spans
-    grp.ok = g + 1 < n_groups && (addr & 15) <= s && nbytes != 0 && nbytes <= STREAM_SPAN;
-    const uint32_t last = grp.ok ? (uint32_t)((nbytes - 1) >> 4) : 0u;
+    grp.base_lo = (uint32_t)base;
+    // not staged: a group whose first chunk would start before the payload (unaligned d_bytes), empty or oversized
+    // spans (and, by the caller, the batch's last group: its final chunk would read past the payload)
+    grp.ok = in_range && mis <= s && nbytes - 1 < C::SPAN;
+    const uint32_t last = grp.ok ? (uint32_t)(nbytes - 1) >> 4 : 0u;
+    const uint8_t* src = grp.ok ? a.bytes + base : (const uint8_t*)a.offsets;
     const uint32_t w = wave_in_block(), t = lane_id();
 #pragma unroll
-    for (uint32_t i = 0; i < 2; ++i) {
-        const uint32_t c = w * 128 + i * 64 + t;
-        const uint8_t* src = grp.ok ? a.bytes + grp.base + 16ull * (c < last ? c : last) : (const uint8_t*)a.offsets;
-        glds16_async(buf + (w * 128 + i * 64) * 4, src);
+    for (uint32_t i = 0; i < (uint32_t)C::RPW; ++i) {
+        const uint32_t c = (w * C::RPW + i) * 64 + t;
+        glds16_async(buf + (w * C::RPW + i) * 256, src + 16 * (c < last ? c : last));
     }
     return grp;
 }
 
-// bytes [rel + 16t, rel + 16t + 16) of the image, rel = c0*16 + a16: two aligned chunks, funnelled by a16 bytes
-CK_DEV u32x4 stream_fetch(const uint32_t* buf, uint32_t c0, uint32_t a16)
-{
-    const uint32_t* p = buf + 4 * (c0 + lane_id());
-    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4], w5 = p[5], w6 = p[6], w7 = p[7];
-    const uint32_t sh = 8 * (a16 & 3);
-    switch (a16 >> 2) {          // wave-uniform
-    case 0: return u32x4{ funnel(w1, w0, 32 - sh) , funnel(w2, w1, 32 - sh), funnel(w3, w2, 32 - sh), funnel(w4, w3, 32 - sh) };
-    case 1: return u32x4{ funnel(w2, w1, 32 - sh) , funnel(w3, w2, 32 - sh), funnel(w4, w3, 32 - sh), funnel(w5, w4, 32 - sh) };
-    case 2: return u32x4{ funnel(w3, w2, 32 - sh) , funnel(w4, w3, 32 - sh), funnel(w5, w4, 32 - sh), funnel(w6, w5, 32 - sh) };
-    default: return u32x4{ funnel(w4, w3, 32 - sh) , funnel(w5, w4, 32 - sh), funnel(w6, w5, 32 - sh), funnel(w7, w6, 32 - sh) };
-    }
-}
-
 // loop of one wave of a workgroup; every wave of the workgroup runs the same number of iterations (barriers inside)
+template <class C, bool HASH>
 CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* ring, uint32_t* blk_count, uint32_t block,
                                    uint32_t nblocks)
 {
-    const uint32_t N = (uint32_t)a.n_records, n_groups = (N + STREAM_GROUP - 1) / STREAM_GROUP;
-    if (block >= n_groups) return;
-    const uint32_t w = wave_in_block();
+    static_assert(C::RPW == 2, "two records per wave per group");
+    constexpr int D = C::NBUF - 1;                    // groups in flight
+    const uint32_t N = (uint32_t)a.n_records, n_groups = (N + C::GROUP - 1) / C::GROUP;
+    if (N == 0) return;
+    const uint32_t n_staged = n_groups - 1;           // the batch's last group is never staged
+    const uint32_t w = wave_in_block(), t = lane_id();
+    if (block == n_staged % nblocks) {                // ...its records go to the general kernel
+        for (uint32_t rec = n_staged * C::GROUP + C::RPW * w; rec < n_staged * C::GROUP + C::RPW * (w + 1) && rec < N; ++rec)
+            defer_record(a, blk_count, block, rec);
+    }
+    if (block >= n_staged) return;
     FastHashConst hc{};
-    if (a.out_hash) hc = fast_hash_const();
-    const bool stores = a.out_bytes != nullptr || a.out_hash != nullptr;
-    // ring state in scalars: cur = the group being processed, nxt = the one in flight behind it
-    StreamGroup cur = stream_issue(a, block, n_groups, ring);
-    StreamGroup nxt = stream_issue(a, block + nblocks, n_groups, ring + STREAM_BUF_DW);
-    vmem_wait<2>();                                  // the first group's two DMAs; the second's may still fly
-    block_barrier();
-    uint32_t bi = 0;                                 // buffer index of cur
-    for (uint32_t g = block; g < n_groups; g += nblocks) {
-        const uint32_t bf = bi ? bi - 1 : STREAM_NBUF - 1;                  // (bi + 2) % 3: the buffer freed last iteration
-        const StreamGroup fut = stream_issue(a, g + 2 * nblocks, n_groups, ring + bf * STREAM_BUF_DW);
-        const uint32_t* img = ring + bi * STREAM_BUF_DW;
-        // this wave's two records of group g
-        const uint64_t ra = (uint64_t)g * STREAM_GROUP + 2 * w;
-        const uint64_t ia = ra < N ? ra : N, ib = ra + 1 < N ? ra + 1 : N, ic = ra + 2 < N ? ra + 2 : N;
-        uint64_t o0, o1, o2, o3;
-        sload_2u64(a.offsets + ia, a.offsets + ib, o0, o1);
-        sload_2u64(a.offsets + ib, a.offsets + ic, o2, o3);
+    if (HASH) hc = fast_hash_const();
+    const bool stores = a.out_bytes || a.out_hash || a.out_index || a.out_strand;     // else only deferrals store
+    // ring state in scalars: q[0] = the group being processed, q[1..D-1] = the ones in flight behind it
+    StreamGroup q[D];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const uint64_t off = k ? o2 : o0;
-            const uint32_t n = (uint32_t)((k ? o3 : o1) - off);
-            const uint32_t rec = (uint32_t)ra + k;
-            if (rec < N) {
-                bool done = false;
-                if (cur.ok && fast_eligible(n)) {
-                    const uint32_t rel = (uint32_t)(off - cur.base);
-                    done = fast_process<false>(a, lut, hc, rec, off, n, stream_fetch(img, rel >> 4, rel & 15));
-                }
-                if (!done) defer_record(a, blk_count, block, rec);
+    for (int d = 0; d < D; ++d) {
+        const uint32_t g = block + d * nblocks, gg = g < n_staged ? g : 0;
+        uint64_t s, e;
+        sload_2u64(a.offsets + (uint64_t)gg * C::GROUP, a.offsets + (uint64_t)gg * C::GROUP + C::GROUP, s, e);
+        q[d] = stream_issue<C>(a, g < n_staged, s, e, ring + d * C::BUF_DW);
+    }
+    vmem_wait<(D - 1) * C::RPW>();                    // the first group's DMAs; the later ones may still fly
+    block_barrier();
+    uint32_t bi = 0;                                  // buffer index of q[0]
+    for (uint32_t g = block; g < n_staged; g += nblocks) {
+        // one scalar round trip per iteration: the span of the group to prefetch and this wave's record offsets
+        const uint32_t gf = g + D * nblocks, gfc = gf < n_staged ? gf : 0;
+        const uint32_t ra = g * C::GROUP + C::RPW * w;
+        uint64_t s, e, o0, o1, o2;
+        sload_group<(int)C::GROUP>(a.offsets + (uint64_t)gfc * C::GROUP, a.offsets + ra, s, e, o0, o1, o2);
+        const uint32_t bf = bi ? bi - 1 : C::NBUF - 1;                     // the buffer freed by the previous iteration
+        const StreamGroup fut = stream_issue<C>(a, gf < n_staged, s, e, ring + bf * C::BUF_DW);
+        const uint32_t* img = ring + bi * C::BUF_DW;
+#pragma unroll
+        for (int k = 0; k < C::RPW; ++k) {
+            const uint64_t off = k ? o1 : o0;
+            const uint32_t n = (uint32_t)(k ? o2 : o1) - (uint32_t)off;
+            const uint32_t rec = ra + k;
+            bool done = false;
+            if (q[0].ok && fast_eligible(n)) {
+                // lane t packs the aligned chunk c0 + t of the image; the record starts a16 bytes into chunk c0, so
+                // the byte funnel is done on the packed words: 2*a16 bits, with the next lane's word behind
+                const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;
+                bool invalid;
+                const uint32_t P = fast_pack(lds_load16(img + 4 * ((rel >> 4) + t)), invalid);
+                // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
+                // record to the general kernel for nothing, which is harmless
+                const uint64_t bad = ballot(invalid) & (nch >= 64 ? ~0ull : (1ull << nch) - 1);
+                done = fast_canon<HASH>(a, lut, hc, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad);
             }
+            if (!done) defer_record(a, blk_count, block, rec);
         }
-        // the next group's DMAs (issued one iteration ago) must have landed.  Younger vector-memory instructions:
-        // the stores of the previous and of this iteration (>= 2 each: every record stores its bytes or hash, or
-        // its deferral; only the batch's last group can hold fewer records, and nothing is waited for after it) and
-        // the two DMAs issued above.
-        if (stores) vmem_wait<6>(); else vmem_wait<2>();
+        // the next group's DMAs (issued D-1 iterations ago) must have landed.  Younger vector-memory instructions:
+        // the DMAs of the D-1 groups issued since, and the stores of this and the D-1 previous iterations (>= RPW
+        // each: every record stores its bytes, hash or index, or its deferral).
+        if (stores) vmem_wait<(2 * D - 1) * C::RPW>(); else vmem_wait<(D - 1) * C::RPW>();
         block_barrier();
-        cur = nxt; nxt = fut;
-        bi = bi + 1 == STREAM_NBUF ? 0 : bi + 1;
+#pragma unroll
+        for (int d = 0; d + 1 < D; ++d) q[d] = q[d + 1];
+        q[D - 1] = fut;
+        bi = bi + 1 == (uint32_t)C::NBUF ? 0 : bi + 1;
     }
 }
 

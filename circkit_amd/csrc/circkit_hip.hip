@@ -21,6 +21,12 @@
 #ifndef CK_STREAM_STAGED
 #define CK_STREAM_STAGED 1   // 1: canon_stream.h (workgroup-staged input); 0: canon_fast.h's per-wave prefetch
 #endif
+#ifndef CK_STREAM_WPB
+#define CK_STREAM_WPB 4      // waves per workgroup of the staged streaming kernel
+#endif
+#ifndef CK_STREAM_NBUF
+#define CK_STREAM_NBUF 3     // LDS images per workgroup (NBUF-1 groups in flight)
+#endif
 #ifndef CK_FAST_BPC
 #define CK_FAST_BPC 64    // workgroups launched per CU (6 resident; the rest queue: finer dynamic balance, measured best of 8..128)
 #endif
@@ -64,17 +70,19 @@ __global__ __launch_bounds__(256, CK_FAST_WPE) void canon_fast_kernel(ck::CanonA
     if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
 }
 
-// The streaming kernel with workgroup-staged input (canon_stream.h): a ring of three 8 KiB images of 8-record groups
-// per workgroup, the decode table and the deferral counter.
-__global__ __launch_bounds__(256, CK_FAST_WPE) void canon_stream_kernel(ck::CanonArgs a)
+// The streaming kernel with workgroup-staged input (canon_stream.h): a ring of images of record groups per
+// workgroup, the decode table and the deferral counter.
+using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF>;
+template <bool HASH>
+__global__ __launch_bounds__(StreamC::WPB * 64, CK_FAST_WPE) void canon_stream_kernel(ck::CanonArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[ck::STREAM_NBUF * ck::STREAM_BUF_DW + 256 + 4];
-    uint32_t* lut = lds + ck::STREAM_NBUF * ck::STREAM_BUF_DW;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW];
+    uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + 256;
-    ck::fast_lut_init(lut, threadIdx.x, 256);
+    ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
     if (threadIdx.x == 0) *blk_count = 0;
     __syncthreads();
-    ck::canon_stream_wave_loop(a, lut, lds, blk_count, blockIdx.x, gridDim.x);
+    ck::canon_stream_wave_loop<StreamC, HASH>(a, lut, lds, blk_count, blockIdx.x, gridDim.x);
     __syncthreads();
     if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
 }
@@ -283,7 +291,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs to
     // workgroup b); the one-wave tiers B, C take 4 segments per workgroup each; tier D is the end of the line
-    const uint64_t per_step = CK_STREAM_STAGED ? ck::STREAM_GROUP : 4;     // records a workgroup takes per iteration
+    const uint64_t per_step = CK_STREAM_STAGED ? StreamC::GROUP : 4;     // records a workgroup takes per iteration
     const uint64_t blocks = (n + per_step - 1) / per_step;
     const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
     const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
@@ -321,7 +329,9 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
-    hipLaunchKernelGGL(CK_STREAM_STAGED ? canon_stream_kernel : canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
+    if (CK_STREAM_STAGED && d_hash) hipLaunchKernelGGL(canon_stream_kernel<true>, dim3(G), dim3(StreamC::WPB * 64), 0, c->stream, a);
+    else if (CK_STREAM_STAGED) hipLaunchKernelGGL(canon_stream_kernel<false>, dim3(G), dim3(StreamC::WPB * 64), 0, c->stream, a);
+    else hipLaunchKernelGGL(canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
     unsigned nseg = G;              // segments / capacity of the list the next tier consumes
     uint32_t seg_cap = cap;
     for (int t = 0; t < N_TIERS; ++t) {

@@ -199,6 +199,32 @@ CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b)
     b = ((uint64_t)r.w << 32) | r.z;
 }
 
+// what one iteration of canon_stream.h needs from the offsets array, with a single wait: p[0] and p[SPAN] (first and
+// one-past-last offset of a record group) and q[0..2] (the offsets of this wave's two records)
+template <int SPAN>
+CK_DEV void sload_group(const uint64_t* p, const uint64_t* q, uint64_t& s, uint64_t& e, uint64_t& o0, uint64_t& o1, uint64_t& o2)
+{
+    uint64_t x, y, z;
+    ck_u32x4v r;
+    asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %4, %6\n\ts_load_dwordx4 %2, %5, 0x0\n\t"
+                 "s_load_dwordx2 %3, %5, 0x10\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(x), "=&s"(y), "=&s"(r), "=&s"(z) : "s"(p), "s"(q), "n"(SPAN * 8) : "memory");
+    s = x; e = y; o2 = z;
+    o0 = ((uint64_t)r.y << 32) | r.x;
+    o1 = ((uint64_t)r.w << 32) | r.z;
+}
+// v_dot4_u32_u8: sum of the four byte products + c.  Through the builtin, never inline asm: on gfx940+ a dot result
+// may be read by another VALU instruction only 3 wait states later, and only the compiler's hazard recognizer
+// inserts those (measured: the asm form returns stale registers).
+CK_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+// 16 bytes from a 16-byte-aligned LDS address: one ds_read_b128 (conflict-free for consecutive lanes)
+CK_DEV u32x4 lds_load16(const uint32_t* p)
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(16)));
+    v4 v = *reinterpret_cast<const v4*>(p);
+    return u32x4{ v.x, v.y, v.z, v.w };
+}
+
 // two independent u64 (e.g. the first and last offset of a record group), one wait
 CK_DEV void sload_2u64(const uint64_t* p0, const uint64_t* p1, uint64_t& a, uint64_t& b)
 {
@@ -324,6 +350,17 @@ template <int N>
 CK_DEV void vmem_wait() {}
 CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b) { a = p[0]; b = p[1]; }
 CK_DEV void sload_2u64(const uint64_t* p0, const uint64_t* p1, uint64_t& a, uint64_t& b) { a = *p0; b = *p1; }
+template <int SPAN>
+CK_DEV void sload_group(const uint64_t* p, const uint64_t* q, uint64_t& s, uint64_t& e, uint64_t& o0, uint64_t& o1, uint64_t& o2)
+{
+    s = p[0]; e = p[SPAN]; o0 = q[0]; o1 = q[1]; o2 = q[2];
+}
+CK_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
+{
+    for (int k = 0; k < 4; ++k) c += ((a >> (8 * k)) & 0xFF) * ((b >> (8 * k)) & 0xFF);
+    return c;
+}
+CK_DEV u32x4 lds_load16(const uint32_t* p) { u32x4 v; memcpy(&v, p, 16); return v; }
 
 }  // namespace ck
 #endif

@@ -12,7 +12,7 @@
 namespace ck { namespace emu {
 // A workgroup = NW waves of 64 fibers.  Wave-level collectives rendezvous the 64 fibers of one wave; block_barrier()
 // rendezvous all fibers of the workgroup.  run_wave() is the 1-wave special case.
-constexpr int MAXW = 4;
+constexpr int MAXW = 8;
 struct WaveSync {
     uint64_t buf[2][64];
     int cnt[2];
@@ -131,11 +131,20 @@ void fast_body(void* p)
     Launch* L = (Launch*)p;
     ck::canon_fast_wave_loop<4>(L->a, L->lut, L->lds, L->blk_count, L->block, L->block * 4 + L->wib, L->nblocks * 4);
 }
-void stream_body(void* p)       // one fiber of a 4-wave workgroup
+template <class C>
+void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
 {
     Launch* L = (Launch*)p;
-    ck::canon_stream_wave_loop(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
+    if (L->a.out_hash) ck::canon_stream_wave_loop<C, true>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
+    else ck::canon_stream_wave_loop<C, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
 }
+// geometries the staged streaming kernel is exercised with (index = `staged` argument - 1)
+struct StreamVariant { void (*body)(void*); int wpb; uint32_t group, lds_dw; };
+template <class C> constexpr StreamVariant variant() { return StreamVariant{ stream_body<C>, C::WPB, C::GROUP, C::LDS_DW }; }
+const StreamVariant kStream[] = {
+    variant<ck::StreamCfg<4, 3>>(), variant<ck::StreamCfg<8, 3>>(), variant<ck::StreamCfg<4, 2>>(),
+    variant<ck::StreamCfg<8, 2>>(), variant<ck::StreamCfg<2, 4>>(), variant<ck::StreamCfg<1, 3>>(),
+};
 }
 
 namespace {
@@ -159,8 +168,11 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
     const uint32_t G = (n_waves + 3) / 4;
-    const uint32_t cap = (uint32_t)(4 * ((n_records + 4ull * G - 1) / (4ull * G))) + 4;
-    std::vector<uint32_t> lds((slice_dw > 3 * ck::STREAM_BUF_DW ? slice_dw : 3 * ck::STREAM_BUF_DW) + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    if (staged < 0 || staged > (int)(sizeof(kStream) / sizeof(kStream[0]))) return -1;
+    const StreamVariant* sv = staged ? &kStream[staged - 1] : nullptr;
+    const uint64_t per_step = sv ? sv->group : 4, steps = (n_records + per_step - 1) / per_step;
+    const uint32_t cap = (uint32_t)(per_step * ((steps + G - 1) / G)) + 4;
+    std::vector<uint32_t> lds((sv && sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[256];
     ck::fast_lut_init(lut, 0, 1);
@@ -177,7 +189,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;
         L.block = b; L.blk_count = &blk;
-        if (staged) ck::emu::run_block(stream_body, &L, 4);
+        if (sv) ck::emu::run_block(sv->body, &L, sv->wpb);
         else for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(fast_body, &L); }
         cnt_f[b] = blk; total_f += blk;
     }

@@ -23,7 +23,11 @@ last_fast_count = 0
 last_fused_hash_count = 0
 
 
-def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=True):
+# `staged`: 0 = canon_fast.h's per-wave prefetch, k >= 1 = canon_stream.h with the k-th geometry (WPB, RPW, NBUF)
+STAGED_GEOMETRIES = {1: (4, 2, 3), 2: (8, 2, 3), 3: (4, 2, 2), 4: (8, 2, 2), 5: (2, 2, 4), 6: (1, 2, 3)}
+
+
+def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
@@ -44,6 +48,7 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data, idx.ctypes.data,
                                      strand.ctypes.data, hs.ctypes.data if want_hash else None,
                                      slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged))
+    assert st >= 0, "emulator rejected the launch (unknown `staged` geometry?)"
     global last_fast_count, last_fused_hash_count
     last_fast_count = nfast.value
     last_fused_hash_count = nfused.value

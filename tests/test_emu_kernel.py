@@ -86,11 +86,13 @@ def test_streaming_kernel_takes_the_headline_records():
     """Pure-ACGT 1 kb records must be handled by the register-resident streaming kernel, not the LDS tier."""
     seqs = seqsets.random_mixed(35, 64, 1000, 1000)
     data, offs = seqsets.pack(seqs)
-    emu.canonicalize_batch(data, offs, staged=False)
+    emu.canonicalize_batch(data, offs, staged=0)
     assert emu.last_fast_count == len(seqs)
-    emu.canonicalize_batch(data, offs, staged=True)
-    assert emu.last_fast_count == len(seqs) - 8     # the batch's last group of 8 is left to the general kernel
-    for staged in (False, True):
+    for k, (wpb, rpw, _) in emu.STAGED_GEOMETRIES.items():
+        emu.canonicalize_batch(data, offs, staged=k)
+        last_group = len(seqs) - (len(seqs) - 1) // (wpb * rpw) * (wpb * rpw)
+        assert emu.last_fast_count == len(seqs) - last_group     # the batch's last group is left to the general kernel
+    for staged in (0, 1):
         emu.canonicalize_batch(*seqsets.pack([b"ACGTN" * 200, b"A" * 500, b"ACGT" * 10, b"ACGT" * 300] * 4), staged=staged)
         assert emu.last_fast_count == 0     # N, repeats, too short, too long -> general kernel
 
@@ -106,3 +108,32 @@ def test_fused_xxh3_matches_oracle():
     assert np.array_equal(out, exp)
     assert np.array_equal(hs, exp_h)
     assert emu.last_fused_hash_count >= 130     # the 241..1008-base pure-ACGT records with a unique minimum
+
+
+@pytest.mark.parametrize("staged", sorted(emu.STAGED_GEOMETRIES))
+def test_staged_streaming_geometries(staged):
+    """canon_stream.h under every workgroup geometry: ragged lengths around the eligibility limits, non-ACGT and
+    periodic records mixed in, batches that end inside a group, workgroups with unequal iteration counts."""
+    rng = np.random.default_rng(900 + staged)
+    for it in range(6):
+        n = int(rng.integers(1, 150))
+        seqs = []
+        for i in range(n):
+            mode = (it + i // 16) % 4
+            if mode == 0: L = 1000
+            elif mode == 1: L = int(rng.integers(48, 1009))
+            elif mode == 2: L = int(rng.choice([0, 1, 15, 16, 17, 47, 48, 49, 240, 241, 1007, 1008, 1009, 1300]))
+            else: L = int(rng.integers(900, 1009))
+            s = bytes(rng.choice(list(b"ACGT" if rng.random() < 0.9 else b"ACGTN-"), size=L).astype(np.uint8))
+            if rng.random() < 0.05 and L >= 8:
+                p = int(rng.integers(1, 9))
+                s = (s[:p] * (L // p + 1))[:L]
+            seqs.append(s)
+        data, offs = seqsets.pack(seqs)
+        out, idx, strand, h, status, _ = emu.canonicalize_batch(data, offs, want_hash=True, staged=staged,
+                                                                n_waves=int(rng.integers(1, 13)))
+        for i, s in enumerate(seqs):
+            a, b = int(offs[i]), int(offs[i + 1])
+            c = O.canonicalize(s)
+            assert out[a:b].tobytes() == c, (it, i, len(s))
+            assert int(h[i]) == O.xxh3_64(c), (it, i, len(s))
