@@ -28,20 +28,20 @@ CK_DEV uint32_t reg_sym_word(uint32_t E, uint32_t p, uint32_t n)
 // shv = 32 - 2*(lane & 15).
 CK_DEV uint32_t fast2_locate(uint32_t E, uint32_t En, uint64_t hm, uint32_t M, uint32_t n, uint32_t shv, bool& unique)
 {
-    const uint32_t l = (uint32_t)ffs64(hm | (1ull << 63));
+    const uint32_t l = (uint32_t)ffs64(hm);                                 // hm != 0: some valid word owns the minimum
     const uint32_t k = lshr64(readlane(E, l), readlane(En, l), shv);
-    const uint32_t left = n - 16 * l;                                       // valid positions in word l
-    uint64_t pm = ballot(k == M) & ((left < 16 ? (1ull << left) : 0x10000ull) - 1);
+    const uint32_t left = n - 16 * l;                                       // valid positions in word l (>= 1)
+    uint32_t pm = (uint32_t)ballot(k == M) & (0xFFFFu >> (16 - (left < 16 ? left : 16)));
     uint32_t cnt = (uint32_t)popc64(pm);
-    uint32_t pos = 16 * l + (uint32_t)ffs64(pm | (1ull << 63));
-    hm &= hm - 1;
-    if (hm) {                                                               // rare
+    uint32_t pos = 16 * l + (uint32_t)ffs64_or_neg(pm);                     // pm == 0: garbage, and cnt says so
+    if (popc64(hm) != 1) {                                                  // rare
+        hm &= hm - 1;
         const uint32_t l2 = (uint32_t)ffs64(hm);
         const uint32_t k2 = lshr64(readlane(E, l2), readlane(En, l2), shv);
         const uint32_t left2 = n - 16 * l2;
-        const uint64_t pm2 = ballot(k2 == M) & ((left2 < 16 ? (1ull << left2) : 0x10000ull) - 1);
+        const uint32_t pm2 = (uint32_t)ballot(k2 == M) & (0xFFFFu >> (16 - (left2 < 16 ? left2 : 16)));
         cnt += (uint32_t)popc64(pm2) + ((hm & (hm - 1)) ? 2u : 0u);         // a third hit lane: give up
-        if (pm == 0) pos = 16 * l2 + (uint32_t)ffs64(pm2 | (1ull << 63));
+        if (pm == 0) pos = 16 * l2 + (uint32_t)ffs64_or_neg(pm2);
     }
     unique = cnt == 1;
     return pos;
@@ -64,26 +64,21 @@ CK_DEV u32x4 fast_fetch(const uint32_t* buf)
     return u32x4{ p[0], p[1], p[2], p[3] };
 }
 
-// 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); `invalid` = this lane holds a byte that is
-// not A/C/G/T.  Per dword: shift+mask to a 3-bit selector, v_perm for the check byte and for the code, one
-// v_bitop3 to accumulate the mismatch, one v_dot4_u32_u8 (weights 64,16,4,1) to gather the four codes into a byte.
-CK_DEV uint32_t fast_pack(u32x4 v, bool& invalid)
+// 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); miss != 0 iff this lane holds a byte that is not
+// A/C/G/T.  Per dword: shift+mask to a 3-bit selector, v_perm for the check byte and for the code, v_sad_u8 to
+// accumulate the mismatch (keeps the ORs off the scalar unit), one v_dot4_u32_u8 (weights 64,16,4,1) to gather the
+// four codes into a byte.
+CK_DEV uint32_t fast_pack(u32x4 v, uint32_t& miss)
 {
     const uint32_t d[4] = { v.x, v.y, v.z, v.w };
-    uint32_t u[4], miss = 0;
+    uint32_t u[4];
+    miss = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t sel = (d[k] >> 1) & HASH_MASK;
-        miss |= perm(0u, CHK2_LO, sel) ^ d[k];
-#ifdef CK_DBG_NO_DOT4
-        const uint32_t code = perm(0u, 0x02030100u, sel);
-        const uint32_t tt = code | (code << 10);
-        u[k] = (tt | (tt << 20)) >> 24;
-#else
+        miss = sad_u8(perm(0u, CHK2_LO, sel), d[k], miss);
         u[k] = udot4(perm(0u, 0x02030100u, sel), 0x01041040u, 0u);
-#endif
     }
-    invalid = miss != 0;
     return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
 }
 
@@ -175,8 +170,9 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
 // ACGT.  Returns false (nothing written) when the record must go to the general kernel: an invalid byte, a minimal
 // key that is not unique, or equal minimal keys on the two strands.  Single exit: the rare failures are folded into
 // one flag instead of early returns, which keeps the scalar unit's branch / mask bookkeeping off the hot path.
-// HASH = false compiles the fused XXH3 out.
-template <bool HASH>
+// HASH = false compiles the fused XXH3 out; AUX = false compiles out what only some callers ask for (rotation index
+// and strand outputs, forward-only mode).
+template <bool HASH, bool AUX>
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
                        uint32_t F, uint64_t bad)
 {
@@ -189,7 +185,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         const uint32_t fix = bfi(~(0xFFFFFFFFu >> (2 * r)), F, B >> (2 * r));
         F = t >= nwv ? ext : (t == nwf ? fix : F);        // r == 0: nwf == nwv, `fix` is never selected
     }
-    const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
+    const bool fwd_only = AUX && (a.flags & CK_FLAG_FWD_ONLY) != 0;
     // reverse-complement strand from the extended forward words:
     // rc word t = comp(reverse(forward symbols [n - 16(t+1), n - 16t) mod n))
     uint32_t C;
@@ -218,7 +214,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
     bool uE, uF = true;
     const uint32_t idx = fast2_locate(E, fwd ? Fn : Cn, fwd ? ballot(mF == MF) : ballot(mC == MC), fwd ? MF : MC, n, shv, uE);
     uint32_t iF = idx;
-    if (a.out_index && !fwd) iF = fast2_locate(F, Fn, ballot(mF == MF), MF, n, shv, uF);
+    if (AUX && a.out_index && !fwd) iF = fast2_locate(F, Fn, ballot(mF == MF), MF, n, shv, uF);
     if (bad != 0 || tie || !uE || !uF) return false;
     {
         // every lane stores a full 16 bytes: the last lane's window is pulled back to end exactly at n, so it
@@ -235,7 +231,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
             }
         }
     }
-    if (t == 0) {
+    if (AUX && t == 0) {
         // unique minimum => period n; idx + iF < 2n
         if (a.out_index) a.out_index[rec] = fwd ? idx : (idx + iF >= n ? idx + iF - n : idx + iF);
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
@@ -248,10 +244,10 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
 CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
                          u32x4 bytes)
 {
-    bool invalid;
-    uint32_t F = fast_pack(bytes, invalid);
+    uint32_t miss;
+    uint32_t F = fast_pack(bytes, miss);
     F <<= lane_id() >= (n >> 4) ? ((16 - (n & 15)) & 15) * 2 : 0;
-    return fast_canon<true>(a, lut, hc, rec, off, n, F, ballot(invalid));
+    return fast_canon<true, true>(a, lut, hc, rec, off, n, F, ballot(miss != 0));
 }
 
 // Software-pipelined grid-stride loop of one wave over a ring of NB 1 KiB LDS buffers: while record k is

@@ -34,32 +34,32 @@ struct StreamGroup {
 };
 
 // DMA of the group whose first / one-past-last offsets are s, e.  Every wave issues exactly RPW instructions (chunks
-// (wave*RPW + i)*64 + lane of the image), whatever the group looks like -- the vmcnt bookkeeping of the loop depends
-// on it.  Lanes past the span re-fetch its last chunk; unstaged groups fetch the offsets array (always readable).
+// (wave*RPW + i)*64 + lane of the image; c16[i] = 16 * that chunk index, precomputed), whatever the group looks like
+// -- the vmcnt bookkeeping of the loop depends on it.  Lanes past the span re-fetch its last chunk; unstaged groups
+// fetch the offsets array (always readable).  All but the per-lane clamp is scalar work.
 template <class C>
-CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, uint64_t e, uint32_t* buf)
+CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, uint64_t e, uint32_t* buf, const uint32_t (&c16)[C::RPW])
 {
+    static_assert((C::SPAN & (C::SPAN - 1)) == 0, "image size must be a power of two");
     const uint32_t mis = ((uint32_t)(uintptr_t)a.bytes + (uint32_t)s) & 15;
     const uint64_t base = s - mis;
-    const uint64_t nbytes = e - base;
+    const uint64_t nb1 = e - base - 1;                // image bytes - 1; wraps to huge for an empty span
     StreamGroup grp;
     grp.base_lo = (uint32_t)base;
     // not staged: a group whose first chunk would start before the payload (unaligned d_bytes), empty or oversized
     // spans (and, by the caller, the batch's last group: its final chunk would read past the payload)
-    grp.ok = in_range && mis <= s && nbytes - 1 < C::SPAN;
-    const uint32_t last = grp.ok ? (uint32_t)(nbytes - 1) >> 4 : 0u;
+    grp.ok = in_range && ((s >> 4) != 0 || (uint32_t)s >= mis) && nb1 / C::SPAN == 0;
+    const uint32_t last16 = grp.ok ? (uint32_t)nb1 & ~15u : 0u;
     const uint8_t* src = grp.ok ? a.bytes + base : (const uint8_t*)a.offsets;
-    const uint32_t w = wave_in_block(), t = lane_id();
+    const uint32_t w = wave_in_block();
 #pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)C::RPW; ++i) {
-        const uint32_t c = (w * C::RPW + i) * 64 + t;
-        glds16_async(buf + (w * C::RPW + i) * 256, src + 16 * (c < last ? c : last));
-    }
+    for (uint32_t i = 0; i < (uint32_t)C::RPW; ++i)
+        glds16_async_s(buf + (w * C::RPW + i) * 256, src, c16[i] < last16 ? c16[i] : last16);
     return grp;
 }
 
 // loop of one wave of a workgroup; every wave of the workgroup runs the same number of iterations (barriers inside)
-template <class C, bool HASH>
+template <class C, bool HASH, bool AUX>
 CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* ring, uint32_t* blk_count, uint32_t block,
                                    uint32_t nblocks)
 {
@@ -77,6 +77,9 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     FastHashConst hc{};
     if (HASH) hc = fast_hash_const();
     const bool stores = a.out_bytes || a.out_hash || a.out_index || a.out_strand;     // else only deferrals store
+    uint32_t c16[C::RPW];
+#pragma unroll
+    for (int i = 0; i < C::RPW; ++i) c16[i] = ((w * C::RPW + i) * 64 + t) * 16;
     // ring state in scalars: q[0] = the group being processed, q[1..D-1] = the ones in flight behind it
     StreamGroup q[D];
 #pragma unroll
@@ -84,7 +87,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         const uint32_t g = block + d * nblocks, gg = g < n_staged ? g : 0;
         uint64_t s, e;
         sload_2u64(a.offsets + (uint64_t)gg * C::GROUP, a.offsets + (uint64_t)gg * C::GROUP + C::GROUP, s, e);
-        q[d] = stream_issue<C>(a, g < n_staged, s, e, ring + d * C::BUF_DW);
+        q[d] = stream_issue<C>(a, g < n_staged, s, e, ring + d * C::BUF_DW, c16);
     }
     vmem_wait<(D - 1) * C::RPW>();                    // the first group's DMAs; the later ones may still fly
     block_barrier();
@@ -96,7 +99,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         uint64_t s, e, o0, o1, o2;
         sload_group<(int)C::GROUP>(a.offsets + (uint64_t)gfc * C::GROUP, a.offsets + ra, s, e, o0, o1, o2);
         const uint32_t bf = bi ? bi - 1 : C::NBUF - 1;                     // the buffer freed by the previous iteration
-        const StreamGroup fut = stream_issue<C>(a, gf < n_staged, s, e, ring + bf * C::BUF_DW);
+        const StreamGroup fut = stream_issue<C>(a, gf < n_staged, s, e, ring + bf * C::BUF_DW, c16);
         const uint32_t* img = ring + bi * C::BUF_DW;
 #pragma unroll
         for (int k = 0; k < C::RPW; ++k) {
@@ -108,12 +111,12 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 // lane t packs the aligned chunk c0 + t of the image; the record starts a16 bytes into chunk c0, so
                 // the byte funnel is done on the packed words: 2*a16 bits, with the next lane's word behind
                 const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;
-                bool invalid;
-                const uint32_t P = fast_pack(lds_load16(img + 4 * ((rel >> 4) + t)), invalid);
+                uint32_t miss;
+                const uint32_t P = fast_pack(lds_load16(img + 4 * ((rel >> 4) + t)), miss);
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
-                const uint64_t bad = ballot(invalid) & (nch >= 64 ? ~0ull : (1ull << nch) - 1);
-                done = fast_canon<HASH>(a, lut, hc, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad);
+                const uint64_t bad = ballot(miss != 0) & (~0ull >> (64 - nch));         // 3 <= nch <= 64
+                done = fast_canon<HASH, AUX>(a, lut, hc, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad);
             }
             if (!done) defer_record(a, blk_count, block, rec);
         }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, CK_FAST_WPE) void canon_fast_kernel(ck::CanonA
 // The streaming kernel with workgroup-staged input (canon_stream.h): a ring of images of record groups per
 // workgroup, the decode table and the deferral counter.
 using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF>;
-template <bool HASH>
+template <bool HASH, bool AUX>
 __global__ __launch_bounds__(StreamC::WPB * 64, CK_FAST_WPE) void canon_stream_kernel(ck::CanonArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW];
@@ -82,22 +82,37 @@ __global__ __launch_bounds__(StreamC::WPB * 64, CK_FAST_WPE) void canon_stream_k
     ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
     if (threadIdx.x == 0) *blk_count = 0;
     __syncthreads();
-    ck::canon_stream_wave_loop<StreamC, HASH>(a, lut, lds, blk_count, blockIdx.x, gridDim.x);
+    ck::canon_stream_wave_loop<StreamC, HASH, AUX>(a, lut, lds, blk_count, blockIdx.x, gridDim.x);
     __syncthreads();
     if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
 }
 
-// XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).
+// XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).  With `hashed` (the flags of
+// the records the streaming kernel hashed itself) a wave takes 64 records at a time, one flag per lane, and only
+// visits the ones still missing -- the pass over an all-hashed batch is one byte load per record.
 __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                                    uint64_t* out, const uint8_t* hashed)
 {
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
-    for (uint64_t r = wave; r < n_records; r += n_waves) {
-        if (hashed && hashed[r]) continue;               // the streaming kernel already hashed this record
-        const uint64_t off = offsets[r];
-        const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
-        if (ck::lane_id() == 0) out[r] = h;
+    if (!hashed) {
+        for (uint64_t r = wave; r < n_records; r += n_waves) {
+            const uint64_t off = offsets[r];
+            const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
+            if (ck::lane_id() == 0) out[r] = h;
+        }
+        return;
+    }
+    for (uint64_t base = (uint64_t)wave * 64; base < n_records; base += (uint64_t)n_waves * 64) {
+        const uint64_t mine = base + ck::lane_id();
+        uint64_t todo = ck::ballot(mine < n_records && !hashed[mine]);
+        while (todo) {
+            const uint64_t r = base + (uint64_t)ck::ffs64(todo);
+            todo &= todo - 1;
+            const uint64_t off = offsets[r];
+            const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
+            if (ck::lane_id() == 0) out[r] = h;
+        }
     }
 }
 
@@ -329,9 +344,17 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
-    if (CK_STREAM_STAGED && d_hash) hipLaunchKernelGGL(canon_stream_kernel<true>, dim3(G), dim3(StreamC::WPB * 64), 0, c->stream, a);
-    else if (CK_STREAM_STAGED) hipLaunchKernelGGL(canon_stream_kernel<false>, dim3(G), dim3(StreamC::WPB * 64), 0, c->stream, a);
-    else hipLaunchKernelGGL(canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
+    if (CK_STREAM_STAGED) {
+        // three builds of the streaming kernel: canonical bytes only (the headline), + fused XXH3 (uniq), and the
+        // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr)
+        const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
+        const dim3 grid(G), block(StreamC::WPB * 64);
+        if (aux) hipLaunchKernelGGL((canon_stream_kernel<true, true>), grid, block, 0, c->stream, a);
+        else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<true, false>), grid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL((canon_stream_kernel<false, false>), grid, block, 0, c->stream, a);
+    } else {
+        hipLaunchKernelGGL(canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
+    }
     unsigned nseg = G;              // segments / capacity of the list the next tier consumes
     uint32_t seg_cap = cap;
     for (int t = 0; t < N_TIERS; ++t) {

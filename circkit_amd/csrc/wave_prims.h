@@ -185,11 +185,20 @@ CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc)
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+// same, source = scalar base + per-lane byte offset (no 64-bit vector address arithmetic); M0 is declared clobbered
+// instead of saved and restored
+CK_DEV void glds16_async_s(uint32_t* lds_dst, const uint8_t* sbase, uint32_t voff)
+{
+    const uint32_t dst = (uint32_t)(uintptr_t)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
+}
 template <int N>
 CK_DEV void vmem_wait()
 {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
+CK_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }   // v_sad_u8
+CK_DEV int ffs64_or_neg(uint64_t v) { return __builtin_ffsll((long long)v) - 1; }      // s_ff1_i32_b64: -1 for 0
 typedef uint32_t ck_u32x4v __attribute__((ext_vector_type(4)));
 CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b)
 {
@@ -346,6 +355,13 @@ CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = 
 CK_DEV uint32_t lds_atomic_inc(uint32_t* p) { return (*p)++; }
 struct ck_u32x4v { uint32_t x, y, z, w; };
 CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), gsrc, 16); }
+CK_DEV void glds16_async_s(uint32_t* lds_dst, const uint8_t* sbase, uint32_t voff) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), sbase + voff, 16); }
+CK_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t acc)
+{
+    for (int k = 0; k < 4; ++k) { int d = (int)((a >> (8 * k)) & 0xFF) - (int)((b >> (8 * k)) & 0xFF); acc += (uint32_t)(d < 0 ? -d : d); }
+    return acc;
+}
+CK_DEV int ffs64_or_neg(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
 template <int N>
 CK_DEV void vmem_wait() {}
 CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b) { a = p[0]; b = p[1]; }

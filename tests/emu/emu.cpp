@@ -135,8 +135,11 @@ template <class C>
 void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
 {
     Launch* L = (Launch*)p;
-    if (L->a.out_hash) ck::canon_stream_wave_loop<C, true>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
-    else ck::canon_stream_wave_loop<C, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
+    // same choice of build as launch_canon()
+    const bool aux = L->a.out_index || L->a.out_strand || (L->a.flags & ck::CK_FLAG_FWD_ONLY);
+    if (aux) ck::canon_stream_wave_loop<C, true, true>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
+    else if (L->a.out_hash) ck::canon_stream_wave_loop<C, true, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
+    else ck::canon_stream_wave_loop<C, false, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
 }
 // geometries the staged streaming kernel is exercised with (index = `staged` argument - 1)
 struct StreamVariant { void (*body)(void*); int wpb; uint32_t group, lds_dw; };

@@ -27,7 +27,7 @@ last_fused_hash_count = 0
 STAGED_GEOMETRIES = {1: (4, 2, 3), 2: (8, 2, 3), 3: (4, 2, 2), 4: (8, 2, 2), 5: (2, 2, 4), 6: (1, 2, 3)}
 
 
-def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1):
+def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1, want_aux=True):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
@@ -45,8 +45,10 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     ndef = ctypes.c_uint32(0)
     nfast = ctypes.c_uint32(0)
     nfused = ctypes.c_uint32(0)
-    st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data, idx.ctypes.data,
-                                     strand.ctypes.data, hs.ctypes.data if want_hash else None,
+    # want_aux=False: no rotation index / strand outputs -- the streaming kernel's leaner builds (see launch_canon)
+    st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data,
+                                     idx.ctypes.data if want_aux else None, strand.ctypes.data if want_aux else None,
+                                     hs.ctypes.data if want_hash else None,
                                      slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged))
     assert st >= 0, "emulator rejected the launch (unknown `staged` geometry?)"
     global last_fast_count, last_fused_hash_count

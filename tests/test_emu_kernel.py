@@ -130,10 +130,15 @@ def test_staged_streaming_geometries(staged):
                 s = (s[:p] * (L // p + 1))[:L]
             seqs.append(s)
         data, offs = seqsets.pack(seqs)
-        out, idx, strand, h, status, _ = emu.canonicalize_batch(data, offs, want_hash=True, staged=staged,
-                                                                n_waves=int(rng.integers(1, 13)))
-        for i, s in enumerate(seqs):
-            a, b = int(offs[i]), int(offs[i + 1])
-            c = O.canonicalize(s)
-            assert out[a:b].tobytes() == c, (it, i, len(s))
-            assert int(h[i]) == O.xxh3_64(c), (it, i, len(s))
+        # the three builds of the kernel: bytes only, bytes + fused XXH3, everything (index / strand)
+        for want_hash, want_aux in ((False, False), (True, False), (True, True)):
+            out, idx, strand, h, status, _ = emu.canonicalize_batch(data, offs, want_hash=want_hash, staged=staged,
+                                                                    want_aux=want_aux, n_waves=int(rng.integers(1, 13)))
+            for i, s in enumerate(seqs):
+                a, b = int(offs[i]), int(offs[i + 1])
+                c, est, eidx = seqsets.expected(O, s)
+                assert out[a:b].tobytes() == c, (it, i, len(s))
+                if want_hash:
+                    assert int(h[i]) == O.xxh3_64(c), (it, i, len(s))
+                if want_aux and len(s):
+                    assert (int(strand[i]), int(idx[i])) == (est, eidx), (it, i, len(s))
