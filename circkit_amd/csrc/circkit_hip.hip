@@ -25,10 +25,10 @@
 #define CK_STREAM_WPB 4      // waves per workgroup of the staged streaming kernel
 #endif
 #ifndef CK_STREAM_NBUF
-#define CK_STREAM_NBUF 3     // LDS images per workgroup (NBUF-1 groups in flight)
+#define CK_STREAM_NBUF 4     // LDS images per workgroup (NBUF-1 groups in flight); 4 x 8 KiB: 4 workgroups per CU
 #endif
 #ifndef CK_FAST_BPC
-#define CK_FAST_BPC 64    // workgroups launched per CU (6 resident; the rest queue: finer dynamic balance, measured best of 8..128)
+#define CK_FAST_BPC 128   // workgroups launched per CU (4-6 resident; the rest queue: finer dynamic balance)
 #endif
 #include "xxh3_core.h"
 

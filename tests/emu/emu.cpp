@@ -145,7 +145,7 @@ void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
 struct StreamVariant { void (*body)(void*); int wpb; uint32_t group, lds_dw; };
 template <class C> constexpr StreamVariant variant() { return StreamVariant{ stream_body<C>, C::WPB, C::GROUP, C::LDS_DW }; }
 const StreamVariant kStream[] = {
-    variant<ck::StreamCfg<4, 3>>(), variant<ck::StreamCfg<8, 3>>(), variant<ck::StreamCfg<4, 2>>(),
+    variant<ck::StreamCfg<4, 4>>(), variant<ck::StreamCfg<8, 3>>(), variant<ck::StreamCfg<4, 2>>(),
     variant<ck::StreamCfg<8, 2>>(), variant<ck::StreamCfg<2, 4>>(), variant<ck::StreamCfg<1, 3>>(),
 };
 }
