@@ -12,6 +12,7 @@
 // program fails like any other I/O error.  Compressed streams are piped through the system's gzip / bzip2 / xz /
 // zstd binaries.
 #include <errno.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -38,6 +39,9 @@ struct Options {
     std::string cmd, input, output, table;
     bool has_input = false, has_output = false, has_table = false, canonicalize = false;
     int threads = 0, device = 0;
+    bool has_bases = false, has_percent = false;        // rotate
+    long long bases = 0;
+    double percent = 0.0;
 };
 
 [[noreturn]] void die(const std::string& msg)
@@ -52,13 +56,19 @@ void usage(FILE* f)
     fprintf(f,
             "circkit (MI355X build)\n\nUSAGE:\n"
             "    circkit canonicalize [INPUT] [-o <OUTPUT>] [-t <THREADS>]\n"
-            "    circkit uniq [INPUT] [-o <OUTPUT>] [-c|--canonicalize] [--table <TABLE>] [-t <THREADS>]\n\n"
+            "    circkit uniq [INPUT] [-o <OUTPUT>] [-c|--canonicalize] [--table <TABLE>] [-t <THREADS>]\n"
+            "    circkit rotate [INPUT] [-o <OUTPUT>] (-b|--bases <N> | -p|--percent <FRACTION>)\n"
+            "    circkit cat [INPUT] [-o <OUTPUT>]\n"
+            "    circkit decat [INPUT] [-o <OUTPUT>]\n\n"
             "    INPUT   FASTA file, may be gzip, bzip, xz, or zstd compressed [default: stdin]\n"
             "    -o      output FASTA path; .gz/.bz2/.xz/.zst compress [default: stdout]\n"
             "    -c      uniq: output canonicalized sequences (aliases --norm --canon)\n"
             "    --table uniq: CSV (TSV for .tsv) of id,duplicate_id\n"
             "    -t      host parser threads [default: logical cores, at most 16]\n"
-            "    --device <N>  GPU index [default: 0]\n");
+            "    --device <N>  GPU index [default: 0]\n"
+            "    -b      rotate: bases to rotate by (positive: to the right, negative: to the left)\n"
+            "    -p      rotate: fraction of the sequence length to rotate by, e.g. 0.5\n"
+            "  canonicalize and uniq run on the GPU; rotate, cat and decat are byte copies done on the host.\n");
 }
 
 Options parse_args(int argc, char** argv)
@@ -67,10 +77,11 @@ Options parse_args(int argc, char** argv)
     if (argc < 2) { usage(stderr); exit(2); }
     o.cmd = argv[1];
     if (o.cmd == "-h" || o.cmd == "--help" || o.cmd == "help") { usage(stdout); exit(0); }
-    if (o.cmd != "canonicalize" && o.cmd != "uniq") {
-        fprintf(stderr, "error: unrecognized subcommand '%s' (this build provides canonicalize and uniq)\n", o.cmd.c_str());
+    if (o.cmd != "canonicalize" && o.cmd != "uniq" && o.cmd != "rotate" && o.cmd != "cat" && o.cmd != "decat") {
+        fprintf(stderr, "error: unrecognized subcommand '%s' (this build provides canonicalize, uniq, rotate, cat, decat)\n", o.cmd.c_str());
         exit(2);
     }
+    const bool gpu_cmd = o.cmd == "canonicalize" || o.cmd == "uniq";
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto value = [&](const char* name) -> std::string {
@@ -79,9 +90,23 @@ Options parse_args(int argc, char** argv)
         };
         if (a == "-o" || a == "--output") { o.output = value("--output"); o.has_output = true; }
         else if (a.rfind("--output=", 0) == 0) { o.output = a.substr(9); o.has_output = true; }
-        else if (a == "-t" || a == "--threads") o.threads = atoi(value("--threads").c_str());
-        else if (a.rfind("--threads=", 0) == 0) o.threads = atoi(a.c_str() + 10);
-        else if (a == "--device") o.device = atoi(value("--device").c_str());
+        else if (gpu_cmd && (a == "-t" || a == "--threads")) o.threads = atoi(value("--threads").c_str());
+        else if (gpu_cmd && a.rfind("--threads=", 0) == 0) o.threads = atoi(a.c_str() + 10);
+        else if (gpu_cmd && a == "--device") o.device = atoi(value("--device").c_str());
+        else if (o.cmd == "rotate" && (a == "-b" || a == "--bases" || a.rfind("--bases=", 0) == 0)) {
+            const std::string v = a.rfind("--bases=", 0) == 0 ? a.substr(8) : value("--bases");      // negative values allowed (src/commands.rs:164)
+            char* end = nullptr;
+            o.bases = strtoll(v.c_str(), &end, 10);
+            if (v.empty() || *end) { fprintf(stderr, "error: invalid value '%s' for '--bases <BASES>'\n", v.c_str()); exit(2); }
+            o.has_bases = true;
+        }
+        else if (o.cmd == "rotate" && (a == "-p" || a == "--percent" || a.rfind("--percent=", 0) == 0)) {
+            const std::string v = a.rfind("--percent=", 0) == 0 ? a.substr(10) : value("--percent");
+            char* end = nullptr;
+            o.percent = strtod(v.c_str(), &end);
+            if (v.empty() || *end) { fprintf(stderr, "error: invalid value '%s' for '--percent <PERCENT>'\n", v.c_str()); exit(2); }
+            o.has_percent = true;
+        }
         else if (o.cmd == "uniq" && (a == "-c" || a == "--canonicalize" || a == "--norm" || a == "--canon")) o.canonicalize = true;
         else if (o.cmd == "uniq" && a == "--table") { o.table = value("--table"); o.has_table = true; }
         else if (o.cmd == "uniq" && a.rfind("--table=", 0) == 0) { o.table = a.substr(8); o.has_table = true; }
@@ -89,6 +114,10 @@ Options parse_args(int argc, char** argv)
         else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); exit(2); }
         else if (!o.has_input) { o.input = a; o.has_input = true; }
         else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); exit(2); }
+    }
+    if (o.has_bases && o.has_percent) {         // src/commands.rs:164,170: the two flags exclude each other
+        fprintf(stderr, "error: the argument '--bases <BASES>' cannot be used with '--percent <PERCENT>'\n");
+        exit(2);
     }
     return o;
 }
@@ -250,6 +279,74 @@ struct Pipeline {
     }
 };
 
+
+// rotate / cat / decat (src/rotate.rs:9-50, src/concatenate.rs:10-54): per-record byte copies of full_seq() -- the
+// sequence lines joined, nothing normalized -- done on the host; there is nothing for a GPU to win on a memcpy that
+// starts and ends in host memory.
+int run_host_edit(const Options& opt, Input& in, Output& out)
+{
+    if (opt.cmd == "rotate" && ((opt.has_bases && opt.bases == 0) || (opt.has_percent && opt.percent == 0.0)))
+        die("Rotation by 0 is not allowed");                                                // src/rotate.rs:20-22
+    std::vector<uint8_t> owned;
+    const uint8_t* text = in.map;
+    size_t len = in.map_len;
+    if (!text) {
+        uint8_t buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, in.f)) > 0) owned.insert(owned.end(), buf, buf + got);
+        text = owned.data();
+        len = owned.size();
+    }
+    ckhost::Batch b;
+    std::string err;
+    size_t used = 0;
+    // a reader error ends the reference's `while let Some(Ok(record))` loop silently; so does it here
+    if (len && ckhost::parse_chunk(text, len, true, true, b, &used, err)) {
+        std::string seq, line;
+        for (size_t i = 0; i < b.n(); ++i) {
+            // full_seq(): the record's lines without their terminators (\n, and a \r before it)
+            seq.clear();
+            const uint8_t* p = text + b.raw[i].off;
+            const size_t n = b.raw[i].len;
+            for (size_t k = 0; k < n;) {
+                const uint8_t* nl = (const uint8_t*)memchr(p + k, '\n', n - k);
+                size_t e = nl ? (size_t)(nl - p) : n;
+                const size_t next = nl ? e + 1 : n;
+                if (e > k && p[e - 1] == '\r') --e;
+                seq.append((const char*)p + k, e - k);
+                k = next;
+            }
+            line.assign(">");
+            line.append((const char*)text + b.head[i].off, b.head[i].len);
+            line += '\n';
+            if (opt.cmd == "cat") { line += seq; line += seq; }
+            else if (opt.cmd == "decat") line.append(seq, 0, seq.size() / 2);
+            else {
+                if (!opt.has_bases && !opt.has_percent) {                                  // src/rotate.rs:29 `expect`
+                    fprintf(stderr, "Must provide either --bases or --percent\n");
+                    _exit(101);
+                }
+                if (seq.empty()) {                                                         // `% 0` panics in the reference
+                    fprintf(stderr, "attempt to calculate the remainder with a divisor of zero\n");
+                    _exit(101);
+                }
+                const long long start = opt.has_percent ? (long long)floor((double)seq.size() * opt.percent) : opt.bases;
+                const size_t L = seq.size();
+                const size_t at = start >= 0 ? L - (size_t)((unsigned long long)start % L)        // src/rotate.rs:37-40
+                                             : (size_t)((0ULL - (unsigned long long)start) % L);
+                line.append(seq, at, std::string::npos);
+                line.append(seq, 0, at);
+            }
+            line += '\n';
+            if (fwrite(line.data(), 1, line.size(), out.f) != line.size()) die("failed to write output");
+        }
+    }
+    close_output(out);
+    if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
+    else if (in.f != stdin) fclose(in.f);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -257,6 +354,7 @@ int main(int argc, char** argv)
     const Options opt = parse_args(argc, argv);
     Input in = open_input(opt);
     Output out = open_output(opt);
+    if (opt.cmd == "rotate" || opt.cmd == "cat" || opt.cmd == "decat") return run_host_edit(opt, in, out);
     FILE* table = nullptr;
     char delim = ',';
     if (opt.has_table) {

@@ -9,6 +9,7 @@ Reference call sites restated here:
   seq_io 0.3.2 FASTA reader semantics  -> read_fasta()
 """
 import ctypes
+import math
 import os
 import subprocess
 
@@ -189,6 +190,42 @@ def cli_canonicalize(data):
         norm, _ = normalize(seq)
         out.append(b">" + head + b"\n" + canonicalize(norm) + b"\n")
     return b"".join(out)
+
+
+def full_seq(raw):
+    """seq_io Record::full_seq(): the record's sequence lines joined, line terminators (\\n, \\r\\n) removed."""
+    return b"".join(l[:-1] if l.endswith(b"\r") else l for l in raw.split(b"\n"))
+
+
+def _read_until_error(data):
+    """`while let Some(Ok(record)) = reader.next()`: a parse error ends the loop silently."""
+    try:
+        return read_fasta(data)
+    except ValueError:
+        return []
+
+
+def cli_rotate(data, bases=None, percent=None):
+    """src/rotate.rs:9-50 on an in-memory FASTA; returns the output file bytes."""
+    if bases == 0 or percent == 0.0:
+        raise ValueError("Rotation by 0 is not allowed")                    # :20-22
+    out = []
+    for head, raw in _read_until_error(data):
+        seq = full_seq(raw)
+        start = int(math.floor(len(seq) * percent)) if percent is not None else bases      # :26-29
+        at = len(seq) - (start % len(seq)) if start >= 0 else (-start) % len(seq)          # :37-40 (ZeroDivisionError = the panic)
+        out.append(b">" + head + b"\n" + seq[at:] + seq[:at] + b"\n")
+    return b"".join(out)
+
+
+def cli_cat(data):
+    """src/concatenate.rs:10-32: every sequence written twice in a row."""
+    return b"".join(b">" + h + b"\n" + full_seq(r) * 2 + b"\n" for h, r in _read_until_error(data))
+
+
+def cli_decat(data):
+    """src/concatenate.rs:34-54: the first half (len / 2, rounded down) of every sequence."""
+    return b"".join(b">" + h + b"\n" + full_seq(r)[:len(full_seq(r)) // 2] + b"\n" for h, r in _read_until_error(data))
 
 
 def cli_uniq(data, canonical_out=False, delimiter=b","):

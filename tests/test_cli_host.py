@@ -1,0 +1,106 @@
+"""rotate / cat / decat: host-only subcommands of the CLI, so these run without a GPU.
+Checked three ways: the oracle restatement against the reference's fixtures (compared the way the reference's own
+tests do: id -> sequence, line breaks ignored, tests/common.rs:32-84), the CLI byte-for-byte against the oracle, and
+the flag / error behaviour of src/rotate.rs and src/commands.rs."""
+import os
+import subprocess
+
+import pytest
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden", "ref_examples")
+BIN = os.path.join(ROOT, "circkit_amd", "circkit")
+
+CASES = [("rotate_5", ["rotate", "--bases", "5"], dict(bases=5)),
+         ("rotate_minus_5", ["rotate", "--bases", "-5"], dict(bases=-5)),
+         ("rotate_0.25", ["rotate", "--percent", "0.25"], dict(percent=0.25)),
+         ("rotate_0.5", ["rotate", "--percent", "0.5"], dict(percent=0.5)),
+         ("cat", ["cat"], None),
+         ("decat", ["decat"], None)]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def cli_binary():
+    from circkit_amd import build
+    build.build_all()
+    assert os.path.exists(BIN)
+
+
+def by_id(data):
+    return {O.record_id(h): O.full_seq(s) for h, s in O.read_fasta(data)}
+
+
+def oracle_out(args, kw, data):
+    if args[0] == "rotate":
+        return O.cli_rotate(data, **kw)
+    return O.cli_cat(data) if args[0] == "cat" else O.cli_decat(data)
+
+
+def run(*args, stdin=None):
+    return subprocess.run([BIN, *args], input=stdin, capture_output=True, timeout=60)
+
+
+@pytest.mark.parametrize("name,args,kw", CASES)
+def test_oracle_matches_the_reference_fixture(name, args, kw):
+    data = open(os.path.join(GOLDEN, name, "in.fasta"), "rb").read()
+    want = open(os.path.join(GOLDEN, name, "out.fasta"), "rb").read()
+    assert by_id(oracle_out(args, kw, data)) == by_id(want)
+
+
+@pytest.mark.parametrize("name,args,kw", CASES)
+def test_cli_matches_oracle_and_fixture(name, args, kw, tmp_path):
+    src = os.path.join(GOLDEN, name, "in.fasta")
+    data = open(src, "rb").read()
+    out = tmp_path / "out.fasta"
+    r = run(*args, src, "-o", str(out))
+    assert (r.returncode, r.stdout, r.stderr) == (0, b"", b"")         # tests/common.rs:17-21
+    got = out.read_bytes()
+    assert got == oracle_out(args, kw, data)
+    assert by_id(got) == by_id(open(os.path.join(GOLDEN, name, "out.fasta"), "rb").read())
+    # stdin -> stdout gives the same bytes
+    r = run(*args, stdin=data)
+    assert r.returncode == 0 and r.stdout == got
+
+
+def test_rotate_semantics():
+    fa = b">a x\nACGT\nAC\n>b\nTTTTG\r\n"
+    for kw, args in ((dict(bases=1), ["-b", "1"]), (dict(bases=-1), ["-b", "-1"]), (dict(bases=6), ["--bases=6"]),
+                     (dict(bases=13), ["-b", "13"]), (dict(bases=-13), ["-b", "-13"]), (dict(percent=0.34), ["-p", "0.34"]),
+                     (dict(percent=1.5), ["--percent=1.5"])):
+        r = run("rotate", *args, stdin=fa)
+        assert r.returncode == 0 and r.stdout == O.cli_rotate(fa, **kw), (kw, r.stdout)
+    assert O.cli_rotate(fa, bases=1) == b">a x\nCACGTA\n>b\nGTTTT\n"       # right rotation: the last base comes first
+    assert O.cli_rotate(fa, bases=-1) == b">a x\nCGTACA\n>b\nTTTGT\n"
+
+
+def test_rotate_errors():
+    r = run("rotate", "-b", "0", stdin=b">a\nACGT\n")
+    assert r.returncode == 1 and r.stdout == b"" and b"Rotation by 0 is not allowed" in r.stderr      # src/rotate.rs:20-22
+    r = run("rotate", "-p", "0", stdin=b">a\nACGT\n")
+    assert r.returncode == 1 and b"Rotation by 0 is not allowed" in r.stderr
+    with pytest.raises(ValueError):
+        O.cli_rotate(b">a\nACGT\n", bases=0)
+    r = run("rotate", "-b", "1", "-p", "0.5", stdin=b">a\nACGT\n")
+    assert r.returncode == 2 and b"cannot be used with" in r.stderr                                     # src/commands.rs:164,170
+    r = run("rotate", stdin=b">a\nACGT\n")
+    assert r.returncode == 101 and b"Must provide either --bases or --percent" in r.stderr             # src/rotate.rs:29 (panic)
+    r = run("rotate", "-b", "x", stdin=b">a\nACGT\n")
+    assert r.returncode == 2
+
+
+def test_cat_decat_edge_cases():
+    for fa in (b"", b">only header", b">e\n\n>odd\nACGTA\n>two lines\nAC\nGT", b"no header\nACGT\n"):
+        r = run("cat", stdin=fa)
+        assert r.returncode == 0 and r.stdout == O.cli_cat(fa), fa
+        r = run("decat", stdin=fa)
+        assert r.returncode == 0 and r.stdout == O.cli_decat(fa), fa
+    assert O.cli_cat(b">odd\nACGTA\n") == b">odd\nACGTAACGTA\n"
+    assert O.cli_decat(b">odd\nACGTA\n") == b">odd\nAC\n"
+    assert O.cli_decat(O.cli_cat(b">x\nAC\nGT\n")) == b">x\nACGT\n"
+
+
+def test_unknown_subcommand_and_flags():
+    assert run("monomerize").returncode == 2
+    assert run("cat", "--threads", "2", stdin=b">a\nA\n").returncode == 2        # cat takes no --threads (src/commands.rs:92-99)
