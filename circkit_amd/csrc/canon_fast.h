@@ -1,11 +1,11 @@
-// canon_fast.h -- the streaming kernel of the canonicalize path.
+// canon_fast.h -- the per-record routine of the streaming kernel of the canonicalize path.
 //
 // Handles the records that make up BASELINE's headline workload -- pure ACGT, 48..1008 bases -- with one
 // packed word per lane held in REGISTERS (no LDS memory; cross-lane access by ds_bpermute / v_readlane,
-// reductions by DPP), straight-line code, and a software pipeline that has the next record's bytes and
-// the record after that's offsets in flight while the current one is computed.  Anything else (other
-// alphabets, longer or shorter records, a repeated minimal key) is appended to a list for the general
-// LDS kernel of canon_core.h.  Same reference functions as there (lib/src/canonicalize.rs:5-63).
+// reductions by DPP) and straight-line code.  How the bytes reach the lanes (workgroup-staged LDS images, the
+// software pipeline) is canon_stream.h.  Anything else (other alphabets, longer or shorter records, a repeated
+// minimal key, equal minimal keys on both strands) is appended to a list for the general LDS kernel of
+// canon_core.h.  Same reference functions as there (lib/src/canonicalize.rs:5-63).
 #pragma once
 #include "canon_core.h"
 #include "xxh3_core.h"
@@ -47,22 +47,8 @@ CK_DEV uint32_t fast2_locate(uint32_t E, uint32_t En, uint64_t hm, uint32_t M, u
     return pos;
 }
 
-// Issue the LDS-DMA prefetch of a record: lane t's 16 input bytes land at buf + 16t.  Eligible record:
-// lanes >= n/16 fetch the record's last 16 bytes (in bounds, n >= 48); their n%16 tail symbols are shifted
-// up later.  Other records: a dummy fetch of the offsets array (always >= 16 readable bytes), so that every
-// call issues exactly one vector-memory instruction -- the pipeline's vmcnt bookkeeping depends on it.
+// records the streaming kernel takes: pure ACGT (checked while packing), one 16-symbol word per lane
 CK_DEV bool fast_eligible(uint32_t n) { return n - FAST_MIN_N <= FAST_MAX_N - FAST_MIN_N; }
-CK_DEV void fast_issue(const CanonArgs& a, uint64_t off, uint32_t n, uint32_t* buf)
-{
-    const uint32_t t = lane_id();
-    const uint8_t* src = fast_eligible(n) ? a.bytes + off + (t >= (n >> 4) ? n - 16 : 16 * t) : (const uint8_t*)a.offsets;
-    glds16_async(buf, src);
-}
-CK_DEV u32x4 fast_fetch(const uint32_t* buf)
-{
-    const uint32_t* p = buf + 4 * lane_id();
-    return u32x4{ p[0], p[1], p[2], p[3] };
-}
 
 // 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); miss != 0 iff this lane holds a byte that is not
 // A/C/G/T.  Per dword: shift+mask to a 3-bit selector, v_perm for the check byte and for the code, v_sad_u8 to
@@ -170,17 +156,42 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
 // ACGT.  Returns false (nothing written) when the record must go to the general kernel: an invalid byte, a minimal
 // key that is not unique, or equal minimal keys on the two strands.  Single exit: the rare failures are folded into
 // one flag instead of early returns, which keeps the scalar unit's branch / mask bookkeeping off the hot path.
+// Lane constants that depend on the record length only (source words and funnel shifts of the periodic extension
+// and of the reverse strand, the byte window each lane stores): recomputed only when the length changes, which on a
+// batch of equal-length records is once per wave.
+struct FastShape {
+    uint32_t n = 0;                 // length these constants are for (0 = none)
+    uint32_t ext_lane;              // t - ceil(n/16): source word of the extension
+    uint32_t rc_lane, rc_sh;        // reverse strand: source word and funnel shift
+    uint32_t out_o;                 // byte offset of this lane's 16 output bytes
+};
+CK_DEV void fast_shape(FastShape& sh, uint32_t n)
+{
+    const uint32_t t = lane_id(), r = n & 15, nwv = (n >> 4) + (r ? 1u : 0u);
+    sh.n = n;
+    sh.ext_lane = t - nwv;
+    // rc word t = comp(reverse(forward symbols [n - 16(t+1), n - 16t) mod n))
+    const int32_t p0 = (int32_t)n - 16 * (int32_t)(t + 1);
+    const uint32_t p = (uint32_t)(p0 + ((p0 >> 31) & (int32_t)n));
+    sh.rc_lane = p >> 4;
+    sh.rc_sh = 32 - (p & 15) * 2;
+    // every lane stores a full 16 bytes: the last lane's window is pulled back to end exactly at n, so it overlaps
+    // its neighbour's with identical bytes -- one store instruction, no partial-store branches
+    sh.out_o = 16 * t + 16 <= n ? 16 * t : n - 16;
+}
+
 // HASH = false compiles the fused XXH3 out; AUX = false compiles out what only some callers ask for (rotation index
 // and strand outputs, forward-only mode).
 template <bool HASH, bool AUX>
-CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
-                       uint32_t F, uint64_t bad)
+CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
+                       uint32_t n, uint32_t F, uint64_t bad)
 {
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
+    if (sh.n != n) fast_shape(sh, n);
     // periodic extension (lanes >= nwf): E[nwf] = r tail symbols ++ head, E[nwv + e] = head shifted by r
     {
-        const uint32_t A = shfl(F, t - nwv), B = shfl(F, t - nwv + 1);
+        const uint32_t A = shfl(F, sh.ext_lane), B = shfl(F, sh.ext_lane + 1);
         const uint32_t ext = lshr64(A, B, 32 - ((16 - r) & 15) * 2);
         const uint32_t fix = bfi(~(0xFFFFFFFFu >> (2 * r)), F, B >> (2 * r));
         F = t >= nwv ? ext : (t == nwf ? fix : F);        // r == 0: nwf == nwv, `fix` is never selected
@@ -190,9 +201,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
     // rc word t = comp(reverse(forward symbols [n - 16(t+1), n - 16t) mod n))
     uint32_t C;
     {
-        const int32_t p0 = (int32_t)n - 16 * (int32_t)(t + 1);
-        const uint32_t p = (uint32_t)(p0 + ((p0 >> 31) & (int32_t)n));
-        const uint32_t g = ~lshr64(shfl(F, p >> 4), shfl(F, (p >> 4) + 1), 32 - (p & 15) * 2);
+        const uint32_t g = ~lshr64(shfl(F, sh.rc_lane), shfl(F, sh.rc_lane + 1), sh.rc_sh);
         const uint32_t v = bitrev(g);                       // reverses bits; swap the two bits of every symbol back
         C = bfi(0x55555555u, v >> 1, v << 1);
     }
@@ -217,9 +226,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
     if (AUX && a.out_index && !fwd) iF = fast2_locate(F, Fn, ballot(mF == MF), MF, n, shv, uF);
     if (bad != 0 || tie || !uE || !uF) return false;
     {
-        // every lane stores a full 16 bytes: the last lane's window is pulled back to end exactly at n, so it
-        // overlaps its neighbour's with identical bytes -- one store instruction, no partial-store branches
-        const uint32_t o = 16 * t + 16 <= n ? 16 * t : n - 16;
+        const uint32_t o = sh.out_o;
         const bool hash = HASH && a.out_hash != nullptr && n > 240;     // XXH3's long-input path; shorter: xxh3 pass
         const bool store = a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL));
         if (store || hash) {
@@ -237,79 +244,6 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
     return true;
-}
-
-// canon_fast's own input: 16 bytes per lane at the record's alignment, lanes >= n/16 loaded with the record's LAST
-// 16 bytes (so every load stays inside the record): their tail symbols are shifted up to the top of the word.
-CK_DEV bool fast_process(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
-                         u32x4 bytes)
-{
-    uint32_t miss;
-    uint32_t F = fast_pack(bytes, miss);
-    F <<= lane_id() >= (n >> 4) ? ((16 - (n & 15)) & 15) * 2 : 0;
-    return fast_canon<true, true>(a, lut, hc, rec, off, n, F, ballot(miss != 0));
-}
-
-// Software-pipelined grid-stride loop of one wave over a ring of NB 1 KiB LDS buffers: while record k is
-// computed, the bytes of records k + stride .. k + (NB-1)*stride are in flight (LDS-DMA); offsets come by
-// scalar load (lgkmcnt, so they never touch the vmcnt bookkeeping).  Memory-level parallelism is what the copy
-// microbenchmark (tools/microbench/copy_bench.hip) shows this chip needs: one 1 KiB request per wave tops
-// out near 4.2 TB/s, several in flight reach 5.4+.
-// vmcnt bookkeeping: every step issues exactly one DMA (depth D = NB-1 ahead).  When record k+1's bytes
-// are needed (end of step k) the vector-memory instructions younger than its DMA are the stores of the last
-// D records and the DMAs of the last D-1 steps.  A record stores at least once when canonical bytes are
-// written (the 16-byte store, or the defer-list store), possibly never otherwise: wait vmcnt(2D-1) resp.
-// vmcnt(D-1).
-struct FastSlot { uint64_t off; uint32_t n; };
-
-template <int NB>
-CK_DEV void fast_step(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t* blk_count, uint32_t block, uint32_t rec,
-                      uint32_t last, uint32_t stride, const FastSlot& cur, uint32_t* cur_buf, FastSlot& fill,
-                      uint32_t* fill_buf)
-{
-    constexpr int D = NB - 1;
-    // offsets of record min(rec + D*stride, last) by scalar load, then its bytes by DMA into the free buffer
-    const uint32_t rn = rec + D * stride;
-    uint64_t o0, o1;
-    sload_u64x2(a.offsets + (rn < last ? rn : last), o0, o1);
-    fill.off = o0;
-    fill.n = (uint32_t)(o1 - o0);
-    fast_issue(a, o0, fill.n, fill_buf);
-    if (!(fast_eligible(cur.n) && fast_process(a, lut, hc, rec, cur.off, cur.n, fast_fetch(cur_buf))))
-        defer_record(a, blk_count, block, rec);
-    if (a.out_bytes || a.out_hash) vmem_wait<2 * D - 1>(); else vmem_wait<D - 1>();
-}
-
-template <int NB>
-CK_DEV void canon_fast_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* lds, uint32_t* blk_count, uint32_t block,
-                                 uint32_t wave_id, uint32_t n_waves)
-{
-    // record indices fit 32 bits (n_records < 2^31 is an ABI precondition); prefetches past the end re-fetch
-    // the last record (harmless, keeps one DMA per step)
-    const uint32_t total = (uint32_t)a.n_records, stride = n_waves, last = total - 1;
-    uint32_t rec = wave_id;
-    if (rec >= total) return;
-    FastHashConst hc{};
-    if (a.out_hash) hc = fast_hash_const();
-    FastSlot s[NB];
-#pragma unroll
-    for (int i = 0; i < NB - 1; ++i) {      // prologue: records rec .. rec + (NB-2)*stride
-        const uint32_t ri = rec + i * stride < last ? rec + i * stride : last;
-        const uint64_t p0 = a.offsets[ri], p1 = a.offsets[ri + 1];
-        s[i].off = p0; s[i].n = (uint32_t)(p1 - p0);
-        fast_issue(a, p0, s[i].n, lds + 256 * i);
-    }
-    vmem_wait<NB - 2>();
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            constexpr int dummy = 0; (void)dummy;
-            const int f = (i + NB - 1) % NB;
-            fast_step<NB>(a, lut, hc, blk_count, block, rec, last, stride, s[i], lds + 256 * i, s[f], lds + 256 * f);
-            rec += stride;
-            if (rec >= total) return;
-        }
-    }
 }
 
 }  // namespace ck

@@ -76,6 +76,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     if (block >= n_staged) return;
     FastHashConst hc{};
     if (HASH) hc = fast_hash_const();
+    FastShape shape;
     const bool stores = a.out_bytes || a.out_hash || a.out_index || a.out_strand;     // else only deferrals store
     uint32_t c16[C::RPW];
 #pragma unroll
@@ -91,8 +92,8 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     }
     vmem_wait<(D - 1) * C::RPW>();                    // the first group's DMAs; the later ones may still fly
     block_barrier();
-    uint32_t bi = 0;                                  // buffer index of q[0]
-    for (uint32_t g = block; g < n_staged; g += nblocks) {
+    uint32_t bi = 0, it = 0;                          // buffer index of q[0]; iteration count
+    for (uint32_t g = block; g < n_staged; g += nblocks, ++it) {
         // one scalar round trip per iteration: the span of the group to prefetch and this wave's record offsets
         const uint32_t gf = g + D * nblocks, gfc = gf < n_staged ? gf : 0;
         const uint32_t ra = g * C::GROUP + C::RPW * w;
@@ -116,14 +117,18 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
                 const uint64_t bad = ballot(miss != 0) & (~0ull >> (64 - nch));         // 3 <= nch <= 64
-                done = fast_canon<HASH, AUX>(a, lut, hc, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad);
+                done = fast_canon<HASH, AUX>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad);
             }
             if (!done) defer_record(a, blk_count, block, rec);
         }
         // the next group's DMAs (issued D-1 iterations ago) must have landed.  Younger vector-memory instructions:
         // the DMAs of the D-1 groups issued since, and the stores of this and the D-1 previous iterations (>= RPW
-        // each: every record stores its bytes, hash or index, or its deferral).
-        if (stores) vmem_wait<(2 * D - 1) * C::RPW>(); else vmem_wait<(D - 1) * C::RPW>();
+        // each: every record stores its bytes, hash or index, or its deferral).  While the next group is still one
+        // of the prologue's (it + 1 < D) there are fewer: the prologue's later DMAs, the DMAs and stores of the
+        // iterations so far -- (D + it) * RPW, of which D * RPW is counted on.
+        if (!stores) vmem_wait<(D - 1) * C::RPW>();
+        else if (it + 1 < (uint32_t)D) vmem_wait<D * C::RPW>();
+        else vmem_wait<(2 * D - 1) * C::RPW>();
         block_barrier();
 #pragma unroll
         for (int d = 0; d + 1 < D; ++d) q[d] = q[d + 1];

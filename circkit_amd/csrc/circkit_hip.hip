@@ -12,14 +12,8 @@
 #include "canon_core.h"
 #include "canon_fast.h"
 #include "canon_stream.h"
-#ifndef CK_FAST_NB
-#define CK_FAST_NB 3
-#endif
 #ifndef CK_FAST_WPE
 #define CK_FAST_WPE 1     // min waves per SIMD the streaming kernel is compiled for
-#endif
-#ifndef CK_STREAM_STAGED
-#define CK_STREAM_STAGED 1   // 1: canon_stream.h (workgroup-staged input); 0: canon_fast.h's per-wave prefetch
 #endif
 #ifndef CK_STREAM_WPB
 #define CK_STREAM_WPB 4      // waves per workgroup of the staged streaming kernel
@@ -50,24 +44,6 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
     ck::canon_wave_loop(a, lds + wib * a.slice_dw, blk_count, blockIdx.x, gridDim.x, wib, WPB);
     __syncthreads();
     if (threadIdx.x == 0 && a.defer_count) a.defer_count[blockIdx.x] = *blk_count;
-}
-
-// The streaming kernel (canon_fast.h): packed words in registers, a ring of FAST_NB 1 KiB LDS buffers per wave
-// for the record prefetch, the 1 KiB decode table and the deferral counter per workgroup.
-constexpr int FAST_NB = CK_FAST_NB;
-__global__ __launch_bounds__(256, CK_FAST_WPE) void canon_fast_kernel(ck::CanonArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 256 * FAST_NB + 256 + 4];
-    uint32_t* lut = lds + 4 * 256 * FAST_NB;
-    uint32_t* blk_count = lut + 256;
-    ck::fast_lut_init(lut, threadIdx.x, 256);
-    if (threadIdx.x == 0) *blk_count = 0;
-    __syncthreads();
-    const uint32_t wib = ck::uniform(threadIdx.x >> 6);
-    const uint32_t wave = ck::uniform(blockIdx.x * 4 + wib);
-    ck::canon_fast_wave_loop<FAST_NB>(a, lut, lds + wib * 256 * FAST_NB, blk_count, blockIdx.x, wave, gridDim.x * 4);
-    __syncthreads();
-    if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
 }
 
 // The streaming kernel with workgroup-staged input (canon_stream.h): a ring of images of record groups per
@@ -306,7 +282,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs to
     // workgroup b); the one-wave tiers B, C take 4 segments per workgroup each; tier D is the end of the line
-    const uint64_t per_step = CK_STREAM_STAGED ? StreamC::GROUP : 4;     // records a workgroup takes per iteration
+    const uint64_t per_step = StreamC::GROUP;                              // records a workgroup takes per iteration
     const uint64_t blocks = (n + per_step - 1) / per_step;
     const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
     const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
@@ -344,7 +320,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
-    if (CK_STREAM_STAGED) {
+    {
         // three builds of the streaming kernel: canonical bytes only (the headline), + fused XXH3 (uniq), and the
         // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr)
         const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
@@ -352,8 +328,6 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         if (aux) hipLaunchKernelGGL((canon_stream_kernel<true, true>), grid, block, 0, c->stream, a);
         else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<true, false>), grid, block, 0, c->stream, a);
         else hipLaunchKernelGGL((canon_stream_kernel<false, false>), grid, block, 0, c->stream, a);
-    } else {
-        hipLaunchKernelGGL(canon_fast_kernel, dim3(G), dim3(256), 0, c->stream, a);
     }
     unsigned nseg = G;              // segments / capacity of the list the next tier consumes
     uint32_t seg_cap = cap;

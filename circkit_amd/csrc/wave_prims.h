@@ -190,6 +190,8 @@ CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc)
 CK_DEV void glds16_async_s(uint32_t* lds_dst, const uint8_t* sbase, uint32_t voff)
 {
     const uint32_t dst = (uint32_t)(uintptr_t)lds_dst;
+    // default cache policy: `nt` on the load and nt / sc1 on the output stores all measured slower (A/B on one box:
+    // 4.32 ms plain, 4.39 nt loads, 4.43 nt stores, 4.98 sc1 stores)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
 }
 template <int N>

@@ -126,11 +126,6 @@ void wave_body(void* p)
     Launch* L = (Launch*)p;
     ck::canon_wave_loop(L->a, L->lds, L->blk_count, L->block, L->nblocks, L->wib, 4);
 }
-void fast_body(void* p)
-{
-    Launch* L = (Launch*)p;
-    ck::canon_fast_wave_loop<4>(L->a, L->lut, L->lds, L->blk_count, L->block, L->block * 4 + L->wib, L->nblocks * 4);
-}
 template <class C>
 void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
 {
@@ -171,11 +166,11 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
     const uint32_t G = (n_waves + 3) / 4;
-    if (staged < 0 || staged > (int)(sizeof(kStream) / sizeof(kStream[0]))) return -1;
-    const StreamVariant* sv = staged ? &kStream[staged - 1] : nullptr;
-    const uint64_t per_step = sv ? sv->group : 4, steps = (n_records + per_step - 1) / per_step;
+    if (staged < 1 || staged > (int)(sizeof(kStream) / sizeof(kStream[0]))) return -1;
+    const StreamVariant* sv = &kStream[staged - 1];
+    const uint64_t per_step = sv->group, steps = (n_records + per_step - 1) / per_step;
     const uint32_t cap = (uint32_t)(per_step * ((steps + G - 1) / G)) + 4;
-    std::vector<uint32_t> lds((sv && sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[256];
     ck::fast_lut_init(lut, 0, 1);
@@ -192,8 +187,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;
         L.block = b; L.blk_count = &blk;
-        if (sv) ck::emu::run_block(sv->body, &L, sv->wpb);
-        else for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(fast_body, &L); }
+        ck::emu::run_block(sv->body, &L, sv->wpb);
         cnt_f[b] = blk; total_f += blk;
     }
     if (n_fast) *n_fast = (uint32_t)n_records - total_f;

@@ -23,7 +23,7 @@ last_fast_count = 0
 last_fused_hash_count = 0
 
 
-# `staged`: 0 = canon_fast.h's per-wave prefetch, k >= 1 = canon_stream.h with the k-th geometry (WPB, RPW, NBUF)
+# `staged`: canon_stream.h's k-th workgroup geometry (WPB, RPW, NBUF), k >= 1
 STAGED_GEOMETRIES = {1: (4, 2, 4), 2: (8, 2, 3), 3: (4, 2, 2), 4: (8, 2, 2), 5: (2, 2, 4), 6: (1, 2, 3)}
 
 
