@@ -27,7 +27,8 @@ last_fused_hash_count = 0
 STAGED_GEOMETRIES = {1: (4, 2, 4), 2: (8, 2, 3), 3: (4, 2, 2), 4: (8, 2, 2), 5: (2, 2, 4), 6: (1, 2, 3)}
 
 
-def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1, want_aux=True):
+def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1, want_aux=True,
+                       base_shift=0, lead=0):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
@@ -36,9 +37,15 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
-    pad = np.zeros(len(data) + 64, dtype=np.uint8)   # same tail padding the device buffers have
-    pad[:len(data)] = data
-    out = np.full(len(data) + 64, 0x3F, dtype=np.uint8)
+    # base_shift: misalignment of the payload pointer; lead: offsets[0] (canary bytes in front of the first record)
+    assert offsets[0] == 0
+    offsets = offsets + np.uint64(lead)
+    raw = np.full(64 + base_shift + lead + len(data) + 64, 0x4E, dtype=np.uint8)
+    skew = (-raw.ctypes.data) % 64 + base_shift         # payload pointer = 64-byte boundary + base_shift
+    pad = raw[skew:]
+    pad[lead:lead + len(data)] = data
+    raw_out = np.full(len(raw), 0x3F, dtype=np.uint8)
+    out = raw_out[skew:]
     idx = np.full(max(n, 1), 0xFFFFFFFF, dtype=np.uint32)
     strand = np.full(max(n, 1), 0xFF, dtype=np.uint8)
     hs = np.zeros(max(n, 1), dtype=np.uint64)
@@ -54,8 +61,8 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     global last_fast_count, last_fused_hash_count
     last_fast_count = nfast.value
     last_fused_hash_count = nfused.value
-    assert (out[len(data):] == 0x3F).all(), "kernel wrote past the end of the output buffer"
-    return out[:len(data)], idx[:n], strand[:n], hs[:n], st, ndef.value
+    assert (out[lead + len(data):] == 0x3F).all() and (raw_out[:skew + lead] == 0x3F).all(), "kernel wrote outside the batch"
+    return out[lead:lead + len(data)], idx[:n], strand[:n], hs[:n], st, ndef.value
 
 
 def xxh3_64(b):

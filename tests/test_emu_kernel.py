@@ -140,3 +140,20 @@ def test_staged_streaming_geometries(staged):
                     assert int(h[i]) == O.xxh3_64(c), (it, i, len(s))
                 if want_aux and len(s):
                     assert (int(strand[i]), int(idx[i])) == (est, eidx), (it, i, len(s))
+
+
+def test_staged_kernel_unaligned_payload_and_nonzero_first_offset():
+    """Payload pointer at any byte alignment, offsets[0] != 0, non-ACGT bytes right in front of / behind the batch:
+    groups whose first chunk would start before the payload are left to the general kernel, nothing outside the
+    batch is written, results unchanged."""
+    seqs = seqsets.random_mixed(950, 90, 48, 1008) + seqsets.random_mixed(951, 10, 1, 47)
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    for shift, lead in ((0, 0), (1, 0), (7, 5), (15, 33), (8, 1000)):
+        for want_aux in (False, True):
+            out, idx, strand, h, status, _ = emu.canonicalize_batch(data, offs, want_hash=True, want_aux=want_aux,
+                                                                    base_shift=shift, lead=lead, n_waves=8)
+            for i, s in enumerate(seqs):
+                a, b = int(offs[i]), int(offs[i + 1])
+                assert out[a:b].tobytes() == want[i], (shift, lead, i, len(s))
+                assert int(h[i]) == O.xxh3_64(want[i])

@@ -335,3 +335,37 @@ def test_pinned_host_buffers(ctx, O):
     assert np.array_equal(got, exp)
     lib.circkit_host_free(pin_in)
     lib.circkit_host_free(pin_out)
+
+
+def test_device_buffers_need_no_alignment_padding_or_zero_base(ctx, O):
+    """The streaming kernel stages 16-byte-aligned chunks of whole record groups; the device API must still accept a
+    payload at any byte alignment, with no slack behind the last record, and offsets that do not start at 0 -- and
+    must never touch a byte outside [offsets[0], offsets[n]) (canaries on both sides, input and output)."""
+    import torch
+    from tests import seqsets
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    seqs = seqsets.random_mixed(71, 700, 48, 1008) + seqsets.random_mixed(72, 60, 1, 60) + [b"ACGTN" * 50, b"A" * 700]
+    data, offs = seqsets.pack(seqs)
+    n, total = len(seqs), len(data)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    for shift, lead in ((0, 0), (1, 0), (7, 5), (15, 33), (8, 1000)):
+        # layout of the device allocation: [shift bytes][lead bytes of canary][payload][canary]
+        buf = torch.full((shift + lead + total + 32,), 0x4E, dtype=torch.uint8, device=dev)      # 'N' canaries
+        view = buf[shift:]
+        view[lead:lead + total] = torch.from_numpy(data).to(dev)
+        d_off = torch.from_numpy((offs + np.uint64(lead)).astype(np.int64)).to(dev)
+        out = torch.full_like(buf, 0x3F)
+        d_hash = torch.empty(n, dtype=torch.int64, device=dev)
+        for want_hash in (False, True):
+            out.fill_(0x3F)
+            ctx.canonicalize_batch_device(view, d_off, n, out_bytes=out[shift:], out_xxh3=d_hash if want_hash else None)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy()
+            lo = shift + lead
+            assert np.array_equal(got[lo:lo + total], exp), (shift, lead, want_hash)
+            assert (got[:lo] == 0x3F).all() and (got[lo + total:] == 0x3F).all(), "wrote outside the batch"
+            if want_hash:
+                assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+        assert (buf[:shift + lead] == 0x4E).all() and (buf[shift + lead + total:] == 0x4E).all()
+    ctx.use_own_stream()
