@@ -22,6 +22,10 @@
 #pragma once
 #include "wave_prims.h"
 
+#ifndef CK_BUILD_ROWS
+#define CK_BUILD_ROWS 4     // rows of 64 packed words whose loads are in flight together in build_packed
+#endif
+
 namespace ck {
 
 struct CanonArgs {
@@ -113,19 +117,6 @@ CK_DEV uint32_t pack2_fwd(u32x4 v, uint32_t& bad)
     }
     return perm(u[0], u[1], 0x07030c0cu) | perm(u[2], u[3], 0x0c0c0703u);
 }
-// Reverse complement of 16 bytes: last byte first, complemented (T0.. -> A3 etc.).
-CK_DEV uint32_t pack2_rc(u32x4 v)
-{
-    uint32_t d[4] = { v.x, v.y, v.z, v.w }, u[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint32_t sel = (d[k] >> 1) & HASH_MASK;
-        uint32_t code = perm(0u, 0x400080C0u, sel);      // comp code << 6: A->3 C->2 T->0 G->1
-        uint32_t t = code | (code << 6);
-        u[k] = t | (t << 12);                             // top byte = b3 b2 b1 b0
-    }
-    return perm(u[3], u[2], 0x07030c0cu) | perm(u[1], u[0], 0x0c0c0703u);
-}
 // 4-bit codes: '-'0 A1 C2 G3 N4 T5.  8 bytes (two dwords) per packed word.
 CK_DEV uint32_t pack4_fwd(uint32_t d0, uint32_t d1, uint32_t& bad)
 {
@@ -152,13 +143,14 @@ template <int BITS>
 CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Er)
 {
     constexpr uint32_t S = 32 / BITS;           // bytes consumed per packed word
+    constexpr bool RC_FROM_FWD = BITS == 2;     // 2-bit complement is `~`: the reverse strand comes from Ef, not from memory
     const uint32_t lane = lane_id();
     const uint32_t nwf = n / S, r = n % S, nwv = nwf + (r ? 1u : 0u);
     uint32_t bad = 0;
-    // Rows of 64 words, four rows per trip with all eight 16-byte loads issued before the first is consumed:
-    // a long record is otherwise one exposed HBM round trip per row (measured: tier B of BASELINE config 4 spent
-    // 61 % of its wave cycles in s_waitcnt with the VALU 20 % busy).
-    constexpr int U = 4;
+    // Rows of 64 words, eight rows (8 KiB of a 2-bit record) per trip with all the 16-byte loads issued before the
+    // first is consumed: a long record is otherwise one exposed HBM round trip per row (measured: tier B of
+    // BASELINE config 4 spent 61 % of its wave cycles in s_waitcnt with the VALU 20 % busy).
+    constexpr int U = CK_BUILD_ROWS;
     for (uint32_t w0 = lane; w0 < nwv; w0 += 64 * U) {
         u32x4 vf[U], vc[U];
 #pragma unroll
@@ -171,7 +163,6 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
                 const uint32_t ra = tail ? 0u : n - S * (w + 1);
                 if (BITS == 2) {
                     vf[u] = load16(src + fa);
-                    vc[u] = load16(src + ra);
                 } else {
                     vf[u] = u32x4{ load4(src + fa), load4(src + fa + 4), 0, 0 };
                     vc[u] = u32x4{ load4(src + ra), load4(src + ra + 4), 0, 0 };
@@ -183,16 +174,12 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
             const uint32_t w = w0 + 64 * u;
             if (w < nwv) {
                 const uint32_t sh = w >= nwf ? (S - r) * BITS : 0u;
-                uint32_t f, c;
                 if (BITS == 2) {
-                    f = pack2_fwd(vf[u], bad);
-                    c = pack2_rc(vc[u]);
+                    Ef[w] = pack2_fwd(vf[u], bad) << sh;
                 } else {
-                    f = pack4_fwd(vf[u].x, vf[u].y, bad);
-                    c = pack4_rc(vc[u].x, vc[u].y);
+                    Ef[w] = pack4_fwd(vf[u].x, vf[u].y, bad) << sh;
+                    Er[w] = pack4_rc(vc[u].x, vc[u].y) << sh;
                 }
-                Ef[w] = f << sh;
-                Er[w] = c << sh;
             }
         }
     }
@@ -201,7 +188,7 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
     // periodic extension: E[nwf] gets the head symbols behind the r tail symbols; E[nwv], E[nwv+1] follow.
     if (lane < 3) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (RC_FROM_FWD ? 1 : 2); ++s) {
             uint32_t* E = s ? Er : Ef;
             if (lane == 0) {
                 if (r) E[nwf] = E[nwf] | (E[0] >> (r * BITS));
@@ -212,6 +199,18 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
         }
     }
     wave_sync();
+    if (RC_FROM_FWD && ok) {
+        // reverse strand, extension words included: word w = comp(reverse(forward symbols [n - 16(w+1), n - 16w)
+        // mod n)); the window may run past the record end into Ef's extension, never past it (n >= 48)
+        for (uint32_t w = lane; w < nwv + 2; w += 64) {
+            const int32_t p0 = (int32_t)n - 16 * (int32_t)(w + 1);
+            const uint32_t p = (uint32_t)(p0 + ((p0 >> 31) & (int32_t)n));
+            const uint32_t g = ~funnel(Ef[p >> 4], Ef[(p >> 4) + 1], (p & 15) * 2);
+            const uint32_t v = bitrev(g);                   // reverses bits; swap the two bits of every symbol back
+            Er[w] = bfi(0x55555555u, v >> 1, v << 1);
+        }
+        wave_sync();
+    }
     return ok;
 }
 
@@ -485,7 +484,8 @@ CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block
     }
 }
 
-// loop of one wave (wave `wib` of `wpb` in workgroup `block` of `nblocks`) over its share of the work
+// loop of one wave (wave `wib` of `wpb` in workgroup `block` of `nblocks`) over its share of the work.
+// (Loading the next record's list entry and offsets one record ahead was tried and measured: no gain.)
 CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t* blk_count, uint32_t block, uint32_t nblocks,
                             uint32_t wib, uint32_t wpb)
 {
