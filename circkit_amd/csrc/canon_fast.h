@@ -105,16 +105,10 @@ CK_DEV FastHashConst fast_hash_const()
     h.i1 = j == 0 ? XP64_1 : j == 1 ? XP64_3 : j == 2 ? XP32_2 : XP32_1;
     return h;
 }
-template <int N>
-CK_DEV uint64_t row_shr_add64(uint64_t v)
-{
-    const uint64_t o = ((uint64_t)dpp_row_shr<N>((uint32_t)(v >> 32)) << 32) | dpp_row_shr<N>((uint32_t)v);
-    return v + o;
-}
 CK_DEV uint64_t shfl_xor_add64(uint64_t v, uint32_t m)
 {
     const uint32_t src = lane_id() ^ m;
-    return v + (((uint64_t)shfl((uint32_t)(v >> 32), src) << 32) | shfl((uint32_t)v, src));
+    return add64_parts(v, shfl((uint32_t)v, src), shfl((uint32_t)(v >> 32), src));
 }
 // `cell` = this lane's 16 canonical bytes [16t, 16t+16) (valid for t < 4*stripes); E / idx = winning strand and
 // rotation; returns the hash (same value in every lane).
@@ -131,8 +125,7 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
         c1 = on ? d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32) : 0;
     }
     // sum over the 16 stripes: lanes t, t+4, t+8, t+12 inside a row (DPP), then the four rows (LDS crossbar)
-    c0 = row_shr_add64<4>(c0); c1 = row_shr_add64<4>(c1);
-    c0 = row_shr_add64<8>(c0); c1 = row_shr_add64<8>(c1);        // lanes 12..15 of each row: row sums of pair t&3
+    dpp_rowsum4_u64x2(c0, c1);                                   // lanes 12..15 of each row: row sums of pair t&3
     c0 = shfl_xor_add64(c0, 16); c1 = shfl_xor_add64(c1, 16);
     c0 = shfl_xor_add64(c0, 32); c1 = shfl_xor_add64(c1, 32);
     uint64_t a0 = hc.i0 + c0, a1 = hc.i1 + c1;                   // meaningful in lanes with (t & 15) >= 12
@@ -145,8 +138,7 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
         a1 += d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32);
     }
     uint64_t r = xfold(a0 ^ hc.m0, a1 ^ hc.m1);                  // merge: sum over the four pairs (one quad)
-    r += ((uint64_t)dpp_quad_xor1((uint32_t)(r >> 32)) << 32) | dpp_quad_xor1((uint32_t)r);
-    r += ((uint64_t)dpp_quad_xor2((uint32_t)(r >> 32)) << 32) | dpp_quad_xor2((uint32_t)r);
+    r = dpp_quadsum_u64(r);
     const uint64_t h = xaval3((uint64_t)n * XP64_1 + r);
     return ((uint64_t)readlane((uint32_t)(h >> 32), 15) << 32) | readlane((uint32_t)h, 15);
 }

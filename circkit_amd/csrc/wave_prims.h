@@ -75,6 +75,51 @@ CK_DEV uint32_t dpp_row_shr(uint32_t v)
 // value of lane i^1 / i^2 (quad_perm)
 CK_DEV uint32_t dpp_quad_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
 CK_DEV uint32_t dpp_quad_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }
+// 64-bit sums along DPP paths with the add fused into the DPP instruction (v_add_co / v_addc_co pairs, 2 VALU per
+// 64-bit add; through update_dpp + uint64_t arithmetic hipcc emits 5).  Two accumulators are interleaved so that
+// each pair fills the other's VALU->DPP wait states.
+//   row sums: lane i += lane i-4, then += lane i-8 of its 16-lane row (lanes 12..15 end up with the sum over
+//   i, i-4, i-8, i-12); lanes that do not exist contribute 0.
+CK_DEV void dpp_rowsum4_u64x2(uint64_t& a, uint64_t& b)
+{
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32), bl = (uint32_t)b, bh = (uint32_t)(b >> 32);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_co_u32_dpp %2, vcc, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_add_co_u32_dpp %2, vcc, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+        "s_nop 1"
+        : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh) :: "vcc");
+    a = ((uint64_t)ah << 32) | al;
+    b = ((uint64_t)bh << 32) | bl;
+}
+//   quad sum: every lane of a quad ends up with the sum over the quad
+CK_DEV uint64_t dpp_quadsum_u64(uint64_t a)
+{
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(al), "+v"(ah) :: "vcc");
+    return ((uint64_t)ah << 32) | al;
+}
+// a + (hi:lo) with the carry chain spelled out (2 VALU)
+CK_DEV uint64_t add64_parts(uint64_t a, uint32_t lo, uint32_t hi)
+{
+    uint32_t al = (uint32_t)a, ah = (uint32_t)(a >> 32);
+    asm("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(al), "+v"(ah) : "v"(lo), "v"(hi) : "vcc");
+    return ((uint64_t)ah << 32) | al;
+}
 // Two independent wave-wide mins at once.  The two DPP chains are interleaved so each fills the other's
 // VALU->DPP wait states (2 needed; one comes from the sibling instruction, one from s_nop 0) and the
 // min is fused into the DPP instruction (hipcc emits v_mov_dpp + v_min otherwise).
@@ -299,6 +344,23 @@ CK_DEV uint32_t dpp_row_shr(uint32_t v)
 }
 CK_DEV uint32_t dpp_quad_xor1(uint32_t v) { uint64_t all[64]; emu::gather(v, all); return (uint32_t)all[lane_id() ^ 1]; }
 CK_DEV uint32_t dpp_quad_xor2(uint32_t v) { uint64_t all[64]; emu::gather(v, all); return (uint32_t)all[lane_id() ^ 2]; }
+CK_DEV void dpp_rowsum4_u64x2(uint64_t& a, uint64_t& b)
+{
+    const uint32_t t = lane_id();
+    uint64_t all[64];
+    for (int step = 4; step <= 8; step += 4) {
+        emu::gather(a, all); a += (t & 15) >= (uint32_t)step ? all[t - step] : 0;
+        emu::gather(b, all); b += (t & 15) >= (uint32_t)step ? all[t - step] : 0;
+    }
+}
+CK_DEV uint64_t dpp_quadsum_u64(uint64_t a)
+{
+    uint64_t all[64];
+    emu::gather(a, all); a += all[lane_id() ^ 1];
+    emu::gather(a, all); a += all[lane_id() ^ 2];
+    return a;
+}
+CK_DEV uint64_t add64_parts(uint64_t a, uint32_t lo, uint32_t hi) { return a + (((uint64_t)hi << 32) | lo); }
 CK_DEV uint32_t wave_shl1(uint32_t v)
 {
     uint64_t all[64]; emu::gather(v, all);
