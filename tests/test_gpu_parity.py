@@ -369,3 +369,16 @@ def test_device_buffers_need_no_alignment_padding_or_zero_base(ctx, O):
                 assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
         assert (buf[:shift + lead] == 0x4E).all() and (buf[shift + lead + total:] == 0x4E).all()
     ctx.use_own_stream()
+
+
+def test_randomized_rare_paths_large():
+    """tools/gpu_fuzz.py: 150k generated records aimed at the streaming kernel's rare paths (planted duplicate minimal
+    16-mers, tandem repeats, reverse-complement palindromes, lengths around every limit, N / '-'), all three builds of
+    the kernel, bytes + XXH3 + index + strand against the oracle.  Run as its own process (it owns its context)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "77", "150000"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout

@@ -1,0 +1,99 @@
+"""GPU box: large randomized parity run of the batch ABI against the oracle (bytes + XXH3, and the bytes-only /
+index builds on a subsample).  Mixtures aimed at the streaming kernel's rare paths: planted duplicate minimal
+16-mers, tandem repeats, reverse-complement palindromes (equal minimal keys on both strands), records around the
+48 / 240 / 1008 limits, N / '-' sprinkled in, lengths 0..1300.
+usage: python tools/gpu_fuzz.py [seed] [records]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process: torch first)
+from circkit_amd import api
+from oracle import oracle as O
+from tests import seqsets
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
+rng = np.random.default_rng(seed)
+LUT = np.frombuffer(b"ACGT", dtype=np.uint8)
+COMP = np.zeros(256, dtype=np.uint8)
+for a, b in zip(b"ACGTN-", b"TGCAN-"):
+    COMP[a] = b
+
+
+def rand(n):
+    return LUT[rng.integers(0, 4, size=n)]
+
+
+seqs = []
+t0 = time.time()
+for i in range(count):
+    k = rng.integers(0, 100)
+    if k < 30: L = 1000
+    elif k < 60: L = int(rng.integers(48, 1009))
+    elif k < 70: L = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 239, 240, 241, 242, 255, 256, 257,
+                                      991, 992, 993, 1006, 1007, 1008, 1009, 1010, 1023, 1024, 1025]))
+    elif k < 80: L = int(rng.integers(1, 1301))
+    else: L = int(rng.integers(60, 400))
+    s = rand(L)
+    m = rng.integers(0, 100)
+    if L >= 64:
+        if m < 8:                                  # the minimal 16-mer planted twice (or more)
+            reps = int(rng.integers(2, 4))
+            w = int(rng.integers(8, 20))
+            for _ in range(reps):
+                p = int(rng.integers(0, L - w))
+                s[p:p + w] = ord("A")
+        elif m < 14:                               # tandem repeat, period p (may or may not divide L)
+            p = int(rng.integers(1, 40))
+            s = np.resize(s[:p], L)
+        elif m < 18:                               # reverse-complement palindrome: both strands give the same rotation set
+            h = s[:L // 2]
+            s = np.concatenate([h, COMP[h][::-1]])
+        elif m < 20:                               # almost periodic: one mismatch at the end
+            p = int(rng.integers(1, 17))
+            s = np.resize(s[:p], L).copy()
+            s[-1] = ord("T") if s[-1] != ord("T") else ord("G")
+        elif m < 25:                               # a few N / '-' somewhere
+            for _ in range(int(rng.integers(1, 4))):
+                s[int(rng.integers(0, len(s)))] = ord("N") if rng.random() < 0.7 else ord("-")
+        elif m < 27:
+            s[:] = ord("A")
+            s[int(rng.integers(0, len(s)))] = ord("C")
+    seqs.append(s.tobytes())
+data, offs = seqsets.pack(seqs)
+print("generated %d records, %d bases in %.1f s" % (count, len(data), time.time() - t0), flush=True)
+t0 = time.time()
+exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=16)
+print("oracle %.1f s" % (time.time() - t0), flush=True)
+ctx = api.Context(0)
+t0 = time.time()
+got = ctx.canonicalize_batch(data, offs, want_bytes=True, want_xxh3=True)
+lean = ctx.canonicalize_batch(data, offs, want_bytes=True)
+full = ctx.canonicalize_batch(data, offs, want_bytes=True, want_index=True, want_strand=True, want_xxh3=True)
+print("gpu (3 builds, host API) %.1f s" % (time.time() - t0), flush=True)
+bad = 0
+for name, r in (("bytes+xxh3", got), ("bytes", lean), ("bytes+xxh3+index+strand", full)):
+    if not np.array_equal(r["bytes"], exp):
+        for i in range(count):
+            a, b = int(offs[i]), int(offs[i + 1])
+            if r["bytes"][a:b].tobytes() != exp[a:b].tobytes():
+                bad += 1
+                if bad < 6:
+                    print("MISMATCH", name, "rec", i, "len", b - a, seqs[i][:60])
+    if r["xxh3"] is not None and not np.array_equal(r["xxh3"], exp_h):
+        w = np.nonzero(r["xxh3"] != exp_h)[0]
+        bad += len(w)
+        print("HASH MISMATCH", name, len(w), "records, first", int(w[0]), "len", len(seqs[int(w[0])]))
+# index / strand against the record-loop restatement on a subsample (python-level oracle calls are slow)
+for i in rng.choice(count, size=min(count, 20000), replace=False):
+    s = seqs[int(i)]
+    _, st, idx = seqsets.expected(O, s)
+    if int(full["strand"][i]) != st or (s and int(full["index"][i]) != idx):
+        bad += 1
+        if bad < 12:
+            print("INDEX/STRAND MISMATCH rec", int(i), "len", len(s), "got", int(full["index"][i]), int(full["strand"][i]), "exp", idx, st)
+print("seed %d: %d records, mismatches: %d" % (seed, count, bad), flush=True)
+sys.exit(1 if bad else 0)
