@@ -138,3 +138,45 @@ def test_not_fasta_is_an_error(tmp_path):
     f.write_bytes(b"ACGT\n")
     r = run("canonicalize", str(f))
     assert r.returncode != 0 and b"Error" in r.stderr
+
+
+def test_large_output_file_vs_stream_vs_oracle(tmp_path):
+    """30k records (two line-wrapped, some with N, duplicates for uniq): a regular output file is written by several
+    threads with positioned writes, stdout by one ordered stream -- both must equal the record-loop restatement byte
+    for byte, for canonicalize and for both uniq modes; appending (`>>`) must append."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(30000):
+        L = int(rng.integers(1, 1400)) if i % 3 else 1000
+        s = bytes(rng.choice(list(b"ACGT" if i % 17 else b"ACGTN"), size=L).astype(np.uint8))
+        if i % 5 == 0 and i:
+            s = recs[int(rng.integers(0, len(recs)))][1]            # duplicate (same orientation is enough here)
+        recs.append((b"r%d some text" % i, s))
+    wrap = lambda s: b"\n".join(s[k:k + 70] for k in range(0, len(s), 70))
+    data = b"".join(b">" + h + b"\n" + (wrap(s) if i % 2 else s) + b"\n" for i, (h, s) in enumerate(recs))
+    src = tmp_path / "in.fasta"
+    src.write_bytes(data)
+    want_c = O.cli_canonicalize(data)
+    for args, want in ((["canonicalize"], want_c), (["uniq"], O.cli_uniq(data)[0]), (["uniq", "-c"], O.cli_uniq(data, True)[0])):
+        out = tmp_path / "out.fasta"
+        r = run(*args, str(src), "-o", str(out))
+        assert r.returncode == 0, r.stderr
+        assert out.read_bytes() == want, args
+        r = run(*args, str(src))
+        assert r.returncode == 0 and r.stdout == want, args
+    # shell append: positioned writes are not used on O_APPEND descriptors
+    out = tmp_path / "app.fasta"
+    out.write_bytes(b">existing\nAC\n")
+    with open(out, "ab") as f:
+        r = subprocess.run([BIN, "canonicalize", str(src)], stdout=f, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0
+    assert out.read_bytes() == b">existing\nAC\n" + want_c
+    # plain redirect into a file that already has content at the current offset: continue from there
+    with open(out, "wb") as f:
+        f.write(b">first\nGG\n")
+        f.flush()
+        r = subprocess.run([BIN, "canonicalize", str(src)], stdout=f, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0
+    assert out.read_bytes() == b">first\nGG\n" + want_c
