@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU")
     ap.add_argument("--length", type=int, default=1000)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="records timed on the host cores (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=3_000_000,
+                    help="records timed on the host cores (rank 0, N=1): ~20 core-seconds of work at the default")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
                     help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
@@ -200,8 +201,12 @@ def main():
             h_out, _ = O.canonicalize_batch(h_in, h_off, True, False, threads=cores)
             cdt = time.perf_counter() - c0
             same = bool(np.array_equal(h_out, d_out[:S * L].cpu().numpy()))
+            S1 = min(S, 100_000)                    # the same restatement on ONE core, smaller sample
+            c1 = time.perf_counter()
+            O.canonicalize_batch(h_in[:S1 * L], h_off[:S1 + 1], True, False, threads=1)
+            one_core = S1 / (time.perf_counter() - c1)
             result["cpu_baseline"] = {
-                "value": S / cdt, "unit": "sequences/s", "cores": cores, "kind": "port",
+                "value": S / cdt, "unit": "sequences/s", "cores": cores, "kind": "port", "one_core_value": one_core,
                 "sample": "first %d records of the same device-generated batch; C restatement of the reference "
                           "path (linear-time byte-indexed Duval variant, faster than the reference's O(n^2) "
                           "chars().nth() loop), %d pthreads" % (S, cores),
