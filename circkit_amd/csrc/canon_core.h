@@ -454,8 +454,9 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
 // Processes one record; returns false if it does not fit this tier's LDS slice.
 CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds)
 {
-    const uint64_t off = a.offsets[rec];
-    const uint32_t n = (uint32_t)(a.offsets[rec + 1] - off);
+    const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
+    if (len >> 31) return false;                 // 32-bit cyclic positions (p < 2n): a record of 2 Gi symbols or more fits nowhere
+    const uint32_t n = (uint32_t)len;
     const uint8_t* src = a.bytes + off;
     if (n == 0) {
         if (lane_id() == 0) {

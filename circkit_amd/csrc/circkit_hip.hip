@@ -46,6 +46,30 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
     if (threadIdx.x == 0 && a.defer_count) a.defer_count[blockIdx.x] = *blk_count;
 }
 
+// The end of the line: records no LDS tier can hold (2-bit beyond ~260 kb).  Same code, one wave per record, with the
+// packed strands and the candidate bitmask in a slice of GLOBAL scratch instead of LDS.  The lanes of one wavefront
+// hand data to each other through that memory; wave_sync()'s wavefront-scope fences are what the AMDGPU memory model
+// asks for there (one wave, one L1, in-order vector memory), so canon_core.h runs unchanged.
+__global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, uint32_t* scratch)
+{
+    __shared__ uint32_t blk_count;
+    if (threadIdx.x == 0) blk_count = 0;
+    __syncthreads();
+    ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, &blk_count, blockIdx.x, gridDim.x, 0, 1);
+}
+
+// XXH3-64 of the listed records (the ones canon_global_kernel finished after the batch's own hash pass)
+__global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, const uint64_t* offsets, const uint32_t* list, uint32_t count,
+                                                      uint64_t* out)
+{
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const uint32_t r = list[i];
+        const uint64_t off = offsets[r];
+        const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
+        if (ck::lane_id() == 0) out[r] = h;
+    }
+}
+
 // The streaming kernel with workgroup-staged input (canon_stream.h): a ring of images of record groups per
 // workgroup, the decode table and the deferral counter.
 using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF>;
@@ -232,6 +256,11 @@ struct circkit_ctx {
     uint64_t cap_bytes = 0, cap_rec = 0;
     uint8_t* d_scratch = nullptr; uint64_t cap_scratch = 0;   // canonical bytes of hash-only batches
     uint8_t* d_hashed = nullptr; uint64_t cap_hashed = 0;     // per record: hash already written by the streaming kernel
+    // records the last LDS tier could not hold: finished by finish_giants() at the next synchronisation point
+    ck::CanonArgs last_args{};
+    uint64_t* last_hash = nullptr;
+    unsigned giant_nseg = 0; uint32_t giant_seg_cap = 0;
+    bool giants_pending = false;
     // uniq table
     unsigned long long *d_keys = nullptr, *d_vals = nullptr;
     uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
@@ -286,7 +315,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     const uint64_t blocks = (n + per_step - 1) / per_step;
     const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
     const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
-    int rc = ensure_lists(c, (uint64_t)G * cap + 64ull * cap, G);
+    int rc = ensure_lists(c, (uint64_t)G * cap + 256ull * cap, G);
     if (rc) return rc;
     if (d_hash && !d_out) {
         // hash-only (uniq without --canonicalize): the canonical bytes go to a ctx-owned scratch the hash kernel
@@ -337,8 +366,9 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const unsigned grid = (nseg + spb - 1) / spb;
         a.list = c->d_lists[t]; a.list_count = c->d_seg_counts + (uint64_t)t * c->seg_alloc;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb;
-        a.defer_list = last ? nullptr : c->d_lists[t + 1];
-        a.defer_count = last ? nullptr : c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
+        // the last tier's leftovers go into the first list (long consumed by now): finish_giants() picks them up
+        a.defer_list = last ? c->d_lists[0] : c->d_lists[t + 1];
+        a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
         a.slice_dw = TIER_DW[t];
         if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), (4 * TIER_DW[t] + 4) * 4, c->stream, a);
@@ -346,12 +376,82 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         nseg = grid;
         seg_cap = spb * seg_cap;
     }
+    c->last_args = a; c->last_hash = d_hash;
+    c->giant_nseg = nseg; c->giant_seg_cap = seg_cap;
+    c->giants_pending = true;
     if (d_hash) {
         hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed);
     }
     CK_HIP(c, hipEventRecord(c->ev1, c->stream));
     CK_HIP(c, hipGetLastError());
     c->timed = true;
+    return CIRCKIT_OK;
+}
+
+// Records beyond the largest LDS tier, found after the batch's kernels have run: read the last tier's leftover list
+// back, size a global scratch for them and run canon_global_kernel (and the hash of their canonical bytes).  Called
+// at every point where the library synchronises with the batch; blocking, and rare by construction.
+int finish_giants(circkit_ctx* c)
+{
+    if (!c->giants_pending) return CIRCKIT_OK;
+    c->giants_pending = false;
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> counts(c->giant_nseg);
+    CK_HIP(c, hipMemcpy(counts.data(), c->d_seg_counts, counts.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> recs;
+    for (unsigned sgm = 0; sgm < c->giant_nseg; ++sgm) {
+        if (!counts[sgm]) continue;
+        const size_t at = recs.size();
+        recs.resize(at + counts[sgm]);
+        CK_HIP(c, hipMemcpy(recs.data() + at, c->d_lists[0] + (uint64_t)sgm * c->giant_seg_cap, counts[sgm] * 4ull, hipMemcpyDeviceToHost));
+    }
+    if (recs.empty()) return CIRCKIT_OK;
+    ck::CanonArgs a = c->last_args;
+    // slice = what the 8-bit mode needs for the longest of them (the largest of the three modes)
+    uint64_t max_len = 0;
+    for (uint32_t r : recs) {
+        uint64_t o[2];
+        CK_HIP(c, hipMemcpy(o, a.offsets + r, 16, hipMemcpyDeviceToHost));
+        if (o[1] - o[0] > max_len) max_len = o[1] - o[0];
+    }
+    uint32_t leftover = 0;
+    if (max_len >> 31) {
+        // cyclic symbol positions (p < 2n) are 32-bit throughout: 2 Gi symbols is the limit of the format
+        leftover = (uint32_t)recs.size();
+    } else {
+        const uint64_t slice = 2 * ((max_len + 3) / 4 + 2) + (max_len + 31) / 32 + 1 + 64;     // ck::need_dw<8>(max_len) + slack
+        unsigned waves = (unsigned)(recs.size() < 64 ? recs.size() : 64);
+        uint32_t* scratch = nullptr;
+        while (waves && hipMalloc(&scratch, slice * 4 * waves) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; waves /= 2; }
+        if (!scratch) return fail(c, CIRCKIT_ERR_OOM, "no memory for the scratch of a %llu-symbol record", (unsigned long long)max_len);
+        uint32_t *d_list = nullptr, *d_ones = nullptr;
+        std::vector<uint32_t> ones(recs.size(), 1u);
+        hipError_t e = hipMalloc(&d_list, recs.size() * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_ones, recs.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(d_list, recs.data(), recs.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_ones, ones.data(), ones.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemsetAsync(c->d_counters + 3, 0, 4, c->stream);
+        if (e == hipSuccess) {
+            // one record per list segment; workgroup b (one wave) takes segments [b*spb, (b+1)*spb)
+            a.list = d_list; a.list_count = d_ones; a.in_nseg = (uint32_t)recs.size(); a.in_seg_cap = 1;
+            a.segs_per_block = (uint32_t)((recs.size() + waves - 1) / waves);
+            a.defer_list = nullptr; a.defer_count = nullptr; a.out_seg_cap = 0;
+            a.slice_dw = (uint32_t)(slice < 0xFFFFFFFFull ? slice : 0xFFFFFFFFull);
+            hipLaunchKernelGGL(canon_global_kernel, dim3(waves), dim3(64), 0, c->stream, a, scratch);
+            if (c->last_hash)
+                hipLaunchKernelGGL(xxh3_list_kernel, dim3(waves), dim3(64), 0, c->stream, a.out_bytes, a.offsets, (const uint32_t*)d_list,
+                                   (uint32_t)recs.size(), c->last_hash);
+            e = hipMemcpyAsync(&leftover, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+        (void)hipFree(scratch); (void)hipFree(d_list); (void)hipFree(d_ones);
+        if (e != hipSuccess) return fail(c, CIRCKIT_ERR_HIP, "long-record pass failed: %s", hipGetErrorString(e));
+    }
+    if (leftover) {
+        // keep the count where circkit_ctx_batch_status() reads it
+        CK_HIP(c, hipMemcpy(c->d_counters + 3, &leftover, 4, hipMemcpyHostToDevice));
+        return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) of 2^31 symbols or more were not processed", leftover);
+    }
     return CIRCKIT_OK;
 }
 
@@ -403,6 +503,7 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
                       strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags);
     if (rc) return rc;
+    if ((rc = finish_giants(c))) return rc;
     if (out && total) CK_HIP(c, hipMemcpyAsync(out, c->d_out, total, hipMemcpyDeviceToHost, c->stream));
     if (idx) CK_HIP(c, hipMemcpyAsync(idx, c->d_idx, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (strand) CK_HIP(c, hipMemcpyAsync(strand, c->d_strand, n, hipMemcpyDeviceToHost, c->stream));
@@ -411,7 +512,7 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     CK_HIP(c, hipMemcpyAsync(&unprocessed, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
     if (unprocessed)
-        return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) exceed the largest LDS tier and were not processed", unprocessed);
+        return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) could not be processed", unprocessed);
     return CIRCKIT_OK;
 }
 
@@ -489,7 +590,7 @@ int circkit_ctx_synchronize(circkit_ctx* c)
     if (!c) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
     CK_HIP(c, hipStreamSynchronize(c->stream));
-    return CIRCKIT_OK;
+    return finish_giants(c);
 }
 
 int circkit_ctx_last_kernel_ms(circkit_ctx* c, float* ms)
@@ -505,6 +606,9 @@ int circkit_ctx_batch_status(circkit_ctx* c, uint32_t* n_unprocessed)
 {
     if (!c || !n_unprocessed) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
+    *n_unprocessed = 0;
+    const int rc = finish_giants(c);
+    if (rc && rc != CIRCKIT_ERR_TOO_LONG) return rc;
     CK_HIP(c, hipMemcpyAsync(n_unprocessed, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
     return *n_unprocessed ? CIRCKIT_ERR_TOO_LONG : CIRCKIT_OK;

@@ -35,7 +35,7 @@ extern "C" {
 #define CIRCKIT_ERR_INVALID_ARG (-1)
 #define CIRCKIT_ERR_NO_DEVICE (-2)   /* no HIP device / device index out of range */
 #define CIRCKIT_ERR_HIP (-3)         /* a HIP runtime call or kernel failed */
-#define CIRCKIT_ERR_TOO_LONG (-4)    /* a record exceeds what one workgroup's LDS can hold */
+#define CIRCKIT_ERR_TOO_LONG (-4)    /* a record of 2^31 symbols or more (cyclic positions are 32-bit) */
 #define CIRCKIT_ERR_OOM (-5)
 #define CIRCKIT_ERR_NOT_ASCII (-6)   /* single-record API only: mirrors the reference's from_utf8().unwrap() panic */
 
@@ -69,7 +69,11 @@ int circkit_ctx_last_kernel_ms(circkit_ctx* ctx, float* ms);
  *                lmsr_index(revcomp(lmsr(s))) -- the two indices the reference computes (:43, :56)
  *   d_out_strand nullable; uint8[n_records]: 0 = lmsr(s) returned, 1 = lmsr(revcomp) returned (:58-62)
  *   d_out_xxh3   nullable; uint64[n_records]: XXH3-64 (seed 0) of the canonical sequence
- * n_records must be < 2^31 and every record shorter than 2^31 bytes. */
+ * n_records must be < 2^31 and every record shorter than 2^31 bytes.  No alignment or padding is required of
+ * d_bytes / d_out_bytes, and offsets[0] need not be 0.
+ * Records too long for the on-chip tiers (pure ACGT beyond ~260 kb, other alphabets beyond ~76-130 kb) are
+ * finished in a global-memory scratch by circkit_ctx_synchronize() / circkit_ctx_batch_status(): call one of them
+ * before consuming a batch that may hold such records, and before enqueuing the next batch on this ctx. */
 int circkit_canonicalize_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                                       uint64_t n_records, uint8_t* d_out_bytes, uint32_t* d_out_index,
                                       uint8_t* d_out_strand, uint64_t* d_out_xxh3);
@@ -82,8 +86,9 @@ int circkit_lmsr_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const ui
 int circkit_xxh3_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                               uint64_t n_records, uint64_t* d_out_xxh3);
 
-/* Number of records of the most recent batch that no LDS tier could hold (they were left untouched);
- * non-zero makes the batch call's status CIRCKIT_ERR_TOO_LONG when queried here.  Synchronizes. */
+/* Completes the most recent batch (synchronizes; runs the long-record pass if that batch needs it) and returns
+ * the number of its records that could not be processed at all (2^31 symbols or more; they were left untouched):
+ * non-zero makes the status CIRCKIT_ERR_TOO_LONG. */
 int circkit_ctx_batch_status(circkit_ctx* ctx, uint32_t* n_unprocessed);
 
 /* ---- batch, host buffers ---------------------------------------------------------------------- */

@@ -138,13 +138,49 @@ def test_lds_tiers_long_records(ctx, O):
     _check(ctx, O, seqs)
 
 
-def test_too_long_record_is_reported_not_dropped_silently(ctx):
-    import circkit_amd
-    n = 2_000_000
-    data = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(1).integers(0, 4, n)]
-    with pytest.raises(circkit_amd.CirckitError) as e:
-        ctx.canonicalize_batch(data, np.array([0, n], dtype=np.uint64))
-    assert e.value.code == -4
+def test_records_beyond_the_lds_tiers(ctx, O):
+    """Records no LDS tier can hold (2-bit beyond ~260 kb, with N beyond ~130 kb, arbitrary bytes beyond ~76 kb) are
+    finished in global scratch by the same code: host API, all outputs; mixed into a batch of ordinary records."""
+    from tests import seqsets
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    big = [acgt[rng.integers(0, 4, 2_000_000)].tobytes(),                # 2 Mb, the record that used to be refused
+           acgt[rng.integers(0, 4, 300_001)].tobytes(),
+           np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 200_000)].tobytes(),
+           rng.integers(1, 128, 100_000).astype(np.uint8).tobytes(),      # arbitrary ASCII: byte mode
+           (acgt[rng.integers(0, 4, 977)].tobytes() * 400)[:390_000],     # long tandem repeat: the duel path, period 977
+           b"A" * 280_000]
+    seqs = seqsets.random_mixed(81, 30, 48, 1008) + big[:3] + seqsets.random_mixed(82, 10, 2000, 9000) + big[3:] + [b"ACGT"]
+    _check(ctx, O, seqs)
+
+
+def test_device_api_finishes_long_records_at_synchronize(ctx, O):
+    """Device API: the batch call stays asynchronous; records beyond the LDS tiers are completed by
+    circkit_ctx_synchronize() / circkit_ctx_batch_status()."""
+    import torch
+    from tests import seqsets
+    rng = np.random.default_rng(4)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = seqsets.random_mixed(83, 20, 900, 1008) + [acgt[rng.integers(0, 4, 700_000)].tobytes()] + seqsets.random_mixed(84, 5, 100, 300)
+    data, offs = seqsets.pack(seqs)
+    n = len(seqs)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_out = torch.zeros_like(d_bytes)
+    d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
+    ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash)
+    assert ctx.batch_status() == 0
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    assert np.array_equal(d_out.cpu().numpy(), exp)
+    assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    # hash-only batch (uniq without --canonicalize): canonical bytes live in the ctx's scratch
+    d_hash.zero_()
+    ctx.canonicalize_batch_device(d_bytes, d_off, n, out_xxh3=d_hash)
+    ctx.synchronize()
+    assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    ctx.use_own_stream()
 
 
 def test_zipf_mixed_lengths_config4_shape(ctx, O):
