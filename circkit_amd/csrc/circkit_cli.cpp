@@ -11,6 +11,7 @@
 // packs CSR batches (fasta_host.h) and writes text out.  There is no CPU compute path: without a usable GPU the
 // program fails like any other I/O error.  Compressed streams are piped through the system's gzip / bzip2 / xz /
 // zstd binaries.
+#include <dlfcn.h>
 #include <errno.h>
 #include <math.h>
 #include <stdio.h>
@@ -19,6 +20,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -129,10 +131,100 @@ std::string shell_quote(const std::string& s)
     return q + "'";
 }
 
+// ---- zstd without the `zstd` binary: libzstd.so.1 (present wherever ROCm is) through dlopen, run as a filter in a
+// forked child so that the pipeline keeps reading / writing a plain pipe.  Only the stable streaming ABI is used.
+struct ZBufIn { const void* src; size_t size, pos; };
+struct ZBufOut { void* dst; size_t size, pos; };
+struct ZstdApi {
+    void* (*createD)(); size_t (*freeD)(void*); size_t (*decompressStream)(void*, ZBufOut*, ZBufIn*);
+    void* (*createC)(); size_t (*freeC)(void*); size_t (*initC)(void*, int);
+    size_t (*compressStream)(void*, ZBufOut*, ZBufIn*); size_t (*endStream)(void*, ZBufOut*);
+    unsigned (*isError)(size_t);
+    bool load()
+    {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW);
+        if (!h) return false;
+#define ZS(f, n) f = (decltype(f))dlsym(h, n); if (!f) return false
+        ZS(createD, "ZSTD_createDStream"); ZS(freeD, "ZSTD_freeDStream"); ZS(decompressStream, "ZSTD_decompressStream");
+        ZS(createC, "ZSTD_createCStream"); ZS(freeC, "ZSTD_freeCStream"); ZS(initC, "ZSTD_initCStream");
+        ZS(compressStream, "ZSTD_compressStream"); ZS(endStream, "ZSTD_endStream"); ZS(isError, "ZSTD_isError");
+#undef ZS
+        return true;
+    }
+};
+bool write_all(int fd, const void* p, size_t n)
+{
+    const char* c = (const char*)p;
+    while (n) {
+        const ssize_t w = write(fd, c, n);
+        if (w < 0) { if (errno == EINTR) continue; return false; }
+        c += w; n -= (size_t)w;
+    }
+    return true;
+}
+// child body: in_fd -> (de)compress -> out_fd; exit code 0 on success
+[[noreturn]] void zstd_filter(const ZstdApi& z, int in_fd, int out_fd, bool compress, int level)
+{
+    std::vector<char> ib(1 << 20), ob(1 << 20);
+    void* st = compress ? z.createC() : z.createD();
+    if (!st || (compress && z.isError(z.initC(st, level)))) _exit(3);
+    bool mid_frame = false;
+    for (;;) {
+        const ssize_t got = read(in_fd, ib.data(), ib.size());
+        if (got < 0) { if (errno == EINTR) continue; _exit(4); }
+        if (got == 0) break;
+        ZBufIn in{ ib.data(), (size_t)got, 0 };
+        while (in.pos < in.size) {
+            ZBufOut out{ ob.data(), ob.size(), 0 };
+            const size_t rc = compress ? z.compressStream(st, &out, &in) : z.decompressStream(st, &out, &in);
+            if (z.isError(rc)) _exit(5);
+            mid_frame = !compress && rc != 0;
+            if (out.pos && !write_all(out_fd, ob.data(), out.pos)) _exit(6);
+        }
+    }
+    if (compress) {
+        for (;;) {
+            ZBufOut out{ ob.data(), ob.size(), 0 };
+            const size_t left = z.endStream(st, &out);
+            if (z.isError(left)) _exit(5);
+            if (out.pos && !write_all(out_fd, ob.data(), out.pos)) _exit(6);
+            if (left == 0) break;
+        }
+    } else if (mid_frame) _exit(7);                    // truncated input
+    _exit(0);
+}
+// forks the filter between `fd` and a new pipe; returns the pipe end the parent uses (read end for decompression,
+// write end for compression) or -1 when libzstd is not there
+int spawn_zstd(int fd, bool compress, int level, pid_t* child)
+{
+    ZstdApi z;
+    if (!z.load()) return -1;
+    int pp[2];
+    if (pipe(pp) != 0) return -1;
+    fflush(stdout); fflush(stderr);
+    const pid_t pid = fork();
+    if (pid < 0) { close(pp[0]); close(pp[1]); return -1; }
+    if (pid == 0) {
+        if (compress) { close(pp[1]); zstd_filter(z, pp[0], fd, true, level); }
+        close(pp[0]); zstd_filter(z, fd, pp[1], false, 0);
+    }
+    *child = pid;
+    close(fd);
+    if (compress) { close(pp[0]); return pp[1]; }
+    close(pp[1]); return pp[0];
+}
+bool reap_zstd(pid_t child)
+{
+    int st = 0;
+    while (waitpid(child, &st, 0) < 0 && errno == EINTR) {}
+    return WIFEXITED(st) && WEXITSTATUS(st) == 0;
+}
+
 // src/utils.rs:9-27: open file or stdin, sniff the compression format by magic bytes (niffler)
 struct Input {
     FILE* f = nullptr;
-    bool piped = false;
+    bool piped = false, zstd_child = false;
+    pid_t zpid = -1;
     const uint8_t* map = nullptr;      // regular uncompressed file: mapped, parsed in place (no read copy)
     size_t map_len = 0;
 };
@@ -173,6 +265,14 @@ Input open_input(const Options& o)
         }
         return in;
     }
+    if (!strcmp(tool, "zstd")) {                    // libzstd in a forked filter; the `zstd` binary only as a fallback
+        const int rfd = dup(fileno(f));
+        if (rfd >= 0 && lseek(rfd, 0, SEEK_SET) == 0) {
+            const int pfd = spawn_zstd(rfd, false, 0, &in.zpid);
+            if (pfd >= 0) { fclose(f); in.f = fdopen(pfd, "rb"); in.zstd_child = true; return in; }
+            close(rfd);
+        }
+    }
     fclose(f);
     const std::string cmd = std::string(tool) + " -dc " + shell_quote(o.input);
     in.f = popen(cmd.c_str(), "r");
@@ -184,7 +284,8 @@ Input open_input(const Options& o)
 // src/utils.rs:29-72: compression by extension with the reference's levels (gz 6, bz2 9, xz 6, zst 1)
 struct Output {
     FILE* f = nullptr;
-    bool piped = false;
+    bool piped = false, zstd_child = false;
+    pid_t zpid = -1;
     std::vector<char> buf;
 };
 
@@ -199,6 +300,18 @@ Output open_output(const Options& o)
     FILE* probe = fopen(p.c_str(), "wb");
     if (!probe) die("Could not create output file " + p + ". Are you sure it's not actually a directory?");   // src/utils.rs:46-49
     if (!tool) { out.f = probe; setvbuf(out.f, out.buf.data(), _IOFBF, out.buf.size()); return out; }
+    if (ends(".zst")) {                              // level 1 (src/utils.rs:58-60) through libzstd, no `zstd` binary needed
+        const int wfd = dup(fileno(probe));
+        const int pfd = wfd >= 0 ? spawn_zstd(wfd, true, 1, &out.zpid) : -1;
+        if (pfd >= 0) {
+            fclose(probe);
+            out.f = fdopen(pfd, "wb");
+            setvbuf(out.f, out.buf.data(), _IOFBF, out.buf.size());
+            out.zstd_child = true;
+            return out;
+        }
+        if (wfd >= 0) close(wfd);
+    }
     fclose(probe);
     const std::string cmd = std::string(tool) + " -c > " + shell_quote(p);
     out.f = popen(cmd.c_str(), "w");
@@ -212,6 +325,7 @@ void close_output(Output& out)
     if (!out.f) return;
     if (fflush(out.f) != 0) die("failed to write output");
     if (out.piped) { if (pclose(out.f) != 0) die("the output compressor failed (is it installed?)"); }
+    else if (out.zstd_child) { fclose(out.f); if (!reap_zstd(out.zpid)) die("zstd compression of the output failed"); }
     else if (out.f != stdout) fclose(out.f);
     out.f = nullptr;
 }
@@ -343,6 +457,7 @@ int run_host_edit(const Options& opt, Input& in, Output& out)
     }
     close_output(out);
     if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
+    else if (in.zstd_child) { fclose(in.f); if (!reap_zstd(in.zpid)) die("zstd decompression of the input failed"); }
     else if (in.f != stdin) fclose(in.f);
     return 0;
 }
@@ -555,6 +670,7 @@ int main(int argc, char** argv)
     close_output(out);
     if (table) fclose(table);
     if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
+    else if (in.zstd_child) { fclose(in.f); if (!reap_zstd(in.zpid)) die("zstd decompression of the input failed"); }
     else if (in.f != stdin) fclose(in.f);
     for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }   // pinned memory goes before the ctx
     circkit_ctx_destroy(ctx);

@@ -104,3 +104,30 @@ def test_cat_decat_edge_cases():
 def test_unknown_subcommand_and_flags():
     assert run("monomerize").returncode == 2
     assert run("cat", "--threads", "2", stdin=b">a\nA\n").returncode == 2        # cat takes no --threads (src/commands.rs:92-99)
+
+
+def test_zstd_streams_without_the_zstd_binary(tmp_path):
+    """.zst in and out go through libzstd.so.1 (dlopen) in a forked filter, level 1 like src/utils.rs:58-60; the
+    reference's compressed fixture decodes, our output decodes with an independent zstd (pyarrow's)."""
+    import numpy as np
+    import pyarrow as pa
+    src = os.path.join(GOLDEN, "compressed_input", "in.fasta.zst")
+    plain = open(os.path.join(GOLDEN, "compressed_input", "in.fasta"), "rb").read()
+    r = run("cat", src)
+    assert r.returncode == 0 and r.stdout == O.cli_cat(plain)
+    # a multi-megabyte stream both ways
+    rng = np.random.default_rng(2)
+    big = b"".join(b">r%d\n" % i + bytes(rng.choice(list(b"ACGT"), size=5000).astype(np.uint8)) + b"\n" for i in range(600))
+    (tmp_path / "big.fasta").write_bytes(big)
+    out = tmp_path / "big_cat.fasta.zst"
+    r = run("cat", str(tmp_path / "big.fasta"), "-o", str(out))
+    assert (r.returncode, r.stdout, r.stderr) == (0, b"", b"")
+    raw = out.read_bytes()
+    assert raw[:4] == b"\x28\xb5\x2f\xfd" and len(raw) < len(big)
+    assert pa.input_stream(pa.BufferReader(raw), compression="zstd").read() == O.cli_cat(big)
+    r = run("decat", str(out))                                  # and back in through the sniffer
+    assert r.returncode == 0 and r.stdout == big
+    # a truncated stream is an error, not a silent short read
+    (tmp_path / "cut.fasta.zst").write_bytes(raw[:len(raw) // 2])
+    r = run("cat", str(tmp_path / "cut.fasta.zst"))
+    assert r.returncode != 0
