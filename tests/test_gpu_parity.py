@@ -418,3 +418,34 @@ def test_randomized_rare_paths_large():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+def test_two_contexts_in_two_threads(O):
+    """include/circkit.h: one host thread per ctx, contexts independent -- two threads, each with its own ctx and
+    stream, running different batches at the same time, get their own results."""
+    import threading
+    import circkit_amd
+    from tests import seqsets
+    results, errors = {}, []
+
+    def work(tag, seed):
+        try:
+            c = circkit_amd.Context(0)
+            for rep in range(4):
+                seqs = seqsets.random_mixed(seed + rep, 3000, 1, 1400) + seqsets.random_mixed(seed + 50 + rep, 200, 48, 1008, b"ACGTN")
+                data, offs = seqsets.pack(seqs)
+                got = c.canonicalize_batch(data, offs, want_bytes=True, want_xxh3=True)
+                exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=2)
+                assert np.array_equal(got["bytes"], exp) and np.array_equal(got["xxh3"], exp_h), (tag, rep)
+            c.close()
+            results[tag] = True
+        except Exception as e:      # noqa: BLE001 -- reported below, on the main thread
+            errors.append((tag, repr(e)))
+
+    ts = [threading.Thread(target=work, args=("a", 500)), threading.Thread(target=work, args=("b", 700))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    assert results == {"a": True, "b": True}
