@@ -23,7 +23,7 @@
 #include "wave_prims.h"
 
 #ifndef CK_BUILD_ROWS
-#define CK_BUILD_ROWS 4     // rows of 64 packed words whose loads are in flight together in build_packed
+#define CK_BUILD_ROWS 6     // rows of 64 packed words whose loads are in flight together in build_packed
 #endif
 
 namespace ck {
@@ -103,20 +103,41 @@ constexpr uint32_t HASH_MASK = 0x07070707u;
 constexpr uint32_t CHK2_LO = 0x47544341u;  // h0..3 -> 'A','C','T','G'
 constexpr uint32_t CHK4_HI = 0x4E2D0000u;  // h6 -> '-', h7 -> 'N'
 
-// 2-bit codes A0 C1 G2 T3.  Forward: first byte -> most significant.
-CK_DEV uint32_t pack2_fwd(u32x4 v, uint32_t& bad)
+// 2-bit codes A0 C1 G2 T3, first byte -> most significant.
+// 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); miss != 0 iff this lane holds a byte that is not
+// A/C/G/T.  Per dword: shift+mask to a 3-bit selector, v_perm for the check byte and for the code, v_sad_u8 to
+// accumulate the mismatch (keeps the ORs off the scalar unit), one v_dot4_u32_u8 (weights 64,16,4,1) to gather the
+// four codes into a byte.
+CK_DEV uint32_t fast_pack(u32x4 v, uint32_t& miss)
 {
-    uint32_t d[4] = { v.x, v.y, v.z, v.w }, u[4];
+    const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+    uint32_t u[4];
+    miss = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        uint32_t sel = (d[k] >> 1) & HASH_MASK;
-        uint32_t code = perm(0u, 0x02030100u, sel);      // A0 C1 T3 G2 at bits 0-1 of each byte
-        bad |= perm(0u, CHK2_LO, sel) ^ d[k];
-        uint32_t t = code | (code << 10);
-        u[k] = t | (t << 20);                             // top byte = b0 b1 b2 b3 (2 bits each)
+        const uint32_t sel = (d[k] >> 1) & HASH_MASK;
+        miss = sad_u8(perm(0u, CHK2_LO, sel), d[k], miss);
+        u[k] = udot4(perm(0u, 0x02030100u, sel), 0x01041040u, 0u);
     }
-    return perm(u[0], u[1], 0x07030c0cu) | perm(u[2], u[3], 0x0c0c0703u);
+    return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
 }
+
+// 256-entry LDS table: packed byte (4 symbols, first in the top bits) -> its 4 ASCII bytes.  Replaces ~6 VALU
+// per output dword (spread the 2-bit fields into bytes, v_perm) by shift + mask + one ds_read_b32.
+CK_DEV void fast_lut_init(uint32_t* lut, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t x = tid; x < 256; x += nthreads) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o |= ((0x54474341u >> (8 * ((x >> (6 - 2 * k)) & 3))) & 0xFFu) << (8 * k);
+        lut[x] = o;
+    }
+}
+CK_DEV u32x4 fast_decode(const uint32_t* lut, uint32_t w)
+{
+    return u32x4{ lut[w >> 24], lut[(w >> 16) & 0xFF], lut[(w >> 8) & 0xFF], lut[w & 0xFF] };
+}
+
 // 4-bit codes: '-'0 A1 C2 G3 N4 T5.  8 bytes (two dwords) per packed word.
 CK_DEV uint32_t pack4_fwd(uint32_t d0, uint32_t d1, uint32_t& bad)
 {
@@ -175,7 +196,9 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
             if (w < nwv) {
                 const uint32_t sh = w >= nwf ? (S - r) * BITS : 0u;
                 if (BITS == 2) {
-                    Ef[w] = pack2_fwd(vf[u], bad) << sh;
+                    uint32_t miss;
+                    Ef[w] = fast_pack(vf[u], miss) << sh;
+                    bad |= miss;
                 } else {
                     Ef[w] = pack4_fwd(vf[u].x, vf[u].y, bad) << sh;
                     Er[w] = pack4_rc(vc[u].x, vc[u].y) << sh;
@@ -388,8 +411,9 @@ CK_DEV void decode4(uint32_t v, uint32_t& lo, uint32_t& hi)
     hi = perm(0x0000544Eu, 0x4743412Du, sb);
 }
 
+// lut: the 256-entry packed-byte -> 4 ASCII bytes table of fast_lut_init() in LDS (2-bit mode), or nullptr
 template <int BITS>
-CK_DEV void emit(const uint32_t* E, uint32_t idx, uint32_t n, uint8_t* out)
+CK_DEV void emit(const uint32_t* E, uint32_t idx, uint32_t n, uint8_t* out, const uint32_t* lut)
 {
     constexpr uint32_t S = 32 / BITS;
     const uint32_t nwv = (n + S - 1) / S;
@@ -398,7 +422,7 @@ CK_DEV void emit(const uint32_t* E, uint32_t idx, uint32_t n, uint8_t* out)
         const uint32_t left = n - w * S;
         u32x4 o{ 0, 0, 0, 0 };
         if (BITS == 2) {
-            o = decode2(v);
+            o = lut ? fast_decode(lut, v) : decode2(v);
         } else if (BITS == 4) {
             decode4(v, o.x, o.y);
         } else {
@@ -420,7 +444,7 @@ CK_DEV uint32_t need_dw(uint32_t n)
 
 template <int BITS>
 CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* src, uint64_t off, uint32_t n,
-                              uint32_t* lds)
+                              uint32_t* lds, const uint32_t* lut)
 {
     constexpr uint32_t S = 32 / BITS;
     const uint32_t nwv = (n + S - 1) / S;
@@ -440,7 +464,7 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
         // lib/src/canonicalize.rs:58-62: forward only if strictly smaller
         fwd = lcp_rot<BITS>(Ef, Er, f.idx, r.idx, n).cmp < 0;
     }
-    if (a.out_bytes) emit<BITS>(fwd ? Ef : Er, fwd ? f.idx : r.idx, n, a.out_bytes + off);
+    if (a.out_bytes) emit<BITS>(fwd ? Ef : Er, fwd ? f.idx : r.idx, n, a.out_bytes + off, lut);
     if (lane_id() == 0) {
         // index as the reference would see it: lmsr_index(s) for the forward strand,
         // lmsr_index(revcomp(lmsr(s))) for the reverse strand (rotation by f.idx, modulo the period)
@@ -452,7 +476,7 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
 
 
 // Processes one record; returns false if it does not fit this tier's LDS slice.
-CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds)
+CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut)
 {
     const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
     if (len >> 31) return false;                 // 32-bit cyclic positions (p < 2n): a record of 2 Gi symbols or more fits nowhere
@@ -467,12 +491,12 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds)
     }
     if (n >= 48) {
         if (need_dw<2>(n) > a.slice_dw) return false;
-        if (canon_record_mode<2>(a, rec, src, off, n, lds)) return true;
+        if (canon_record_mode<2>(a, rec, src, off, n, lds, lut)) return true;
         if (need_dw<4>(n) > a.slice_dw) return false;
-        if (canon_record_mode<4>(a, rec, src, off, n, lds)) return true;
+        if (canon_record_mode<4>(a, rec, src, off, n, lds, lut)) return true;
     }
     if (need_dw<8>(n) > a.slice_dw) return false;
-    canon_record_mode<8>(a, rec, src, off, n, lds);
+    canon_record_mode<8>(a, rec, src, off, n, lds, lut);
     return true;
 }
 
@@ -487,12 +511,12 @@ CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block
 
 // loop of one wave (wave `wib` of `wpb` in workgroup `block` of `nblocks`) over its share of the work.
 // (Loading the next record's list entry and offsets one record ahead was tried and measured: no gain.)
-CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t* blk_count, uint32_t block, uint32_t nblocks,
-                            uint32_t wib, uint32_t wpb)
+CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, uint32_t* blk_count, uint32_t block,
+                            uint32_t nblocks, uint32_t wib, uint32_t wpb)
 {
     if (!a.list) {
         for (uint64_t rec = (uint64_t)block * wpb + wib; rec < a.n_records; rec += (uint64_t)nblocks * wpb) {
-            if (!canon_record(a, rec, lds)) defer_record(a, blk_count, block, (uint32_t)rec);
+            if (!canon_record(a, rec, lds, lut)) defer_record(a, blk_count, block, (uint32_t)rec);
             wave_sync();
         }
         return;
@@ -502,7 +526,7 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, uint32_t* blk_cou
         const uint32_t* seg = a.list + (uint64_t)s * a.in_seg_cap;
         for (uint32_t i = wib; i < count; i += wpb) {
             const uint32_t rec = seg[i];
-            if (!canon_record(a, rec, lds)) defer_record(a, blk_count, block, rec);
+            if (!canon_record(a, rec, lds, lut)) defer_record(a, blk_count, block, rec);
             wave_sync();
         }
     }

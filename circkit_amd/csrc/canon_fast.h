@@ -50,40 +50,6 @@ CK_DEV uint32_t fast2_locate(uint32_t E, uint32_t En, uint64_t hm, uint32_t M, u
 // records the streaming kernel takes: pure ACGT (checked while packing), one 16-symbol word per lane
 CK_DEV bool fast_eligible(uint32_t n) { return n - FAST_MIN_N <= FAST_MAX_N - FAST_MIN_N; }
 
-// 16 ASCII bytes -> 16 two-bit codes (first byte in the top bits); miss != 0 iff this lane holds a byte that is not
-// A/C/G/T.  Per dword: shift+mask to a 3-bit selector, v_perm for the check byte and for the code, v_sad_u8 to
-// accumulate the mismatch (keeps the ORs off the scalar unit), one v_dot4_u32_u8 (weights 64,16,4,1) to gather the
-// four codes into a byte.
-CK_DEV uint32_t fast_pack(u32x4 v, uint32_t& miss)
-{
-    const uint32_t d[4] = { v.x, v.y, v.z, v.w };
-    uint32_t u[4];
-    miss = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t sel = (d[k] >> 1) & HASH_MASK;
-        miss = sad_u8(perm(0u, CHK2_LO, sel), d[k], miss);
-        u[k] = udot4(perm(0u, 0x02030100u, sel), 0x01041040u, 0u);
-    }
-    return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
-}
-
-// 256-entry LDS table: packed byte (4 symbols, first in the top bits) -> its 4 ASCII bytes.  Replaces ~6 VALU
-// per output dword (spread the 2-bit fields into bytes, v_perm) by shift + mask + one ds_read_b32.
-CK_DEV void fast_lut_init(uint32_t* lut, uint32_t tid, uint32_t nthreads)
-{
-    for (uint32_t x = tid; x < 256; x += nthreads) {
-        uint32_t o = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) o |= ((0x54474341u >> (8 * ((x >> (6 - 2 * k)) & 3))) & 0xFFu) << (8 * k);
-        lut[x] = o;
-    }
-}
-CK_DEV u32x4 fast_decode(const uint32_t* lut, uint32_t w)
-{
-    return u32x4{ lut[w >> 24], lut[(w >> 16) & 0xFF], lut[(w >> 8) & 0xFF], lut[w & 0xFF] };
-}
-
 // ---- XXH3-64 fused into the streaming kernel (records of 241..1008 bytes: one 1024-byte block, no scramble) ----
 // Replaces `xxh3_64(canonicalized)` (src/uniq.rs:45) without re-reading the canonical bytes: lane t already holds
 // bytes [16t, 16t+16) of the output = cell (stripe t>>2, accumulator pair t&3) of XXH3's long-input loop.

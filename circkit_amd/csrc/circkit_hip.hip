@@ -38,10 +38,12 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + WPB * a.slice_dw;
+    uint32_t* lut = blk_count + 4;                   // 2-bit decode table shared by the workgroup's waves
+    ck::fast_lut_init(lut, threadIdx.x, WPB * 64);
     if (threadIdx.x == 0) *blk_count = 0;
     __syncthreads();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
-    ck::canon_wave_loop(a, lds + wib * a.slice_dw, blk_count, blockIdx.x, gridDim.x, wib, WPB);
+    ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, blockIdx.x, gridDim.x, wib, WPB);
     __syncthreads();
     if (threadIdx.x == 0 && a.defer_count) a.defer_count[blockIdx.x] = *blk_count;
 }
@@ -52,10 +54,11 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
 // asks for there (one wave, one L1, in-order vector memory), so canon_core.h runs unchanged.
 __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, uint32_t* scratch)
 {
-    __shared__ uint32_t blk_count;
+    __shared__ uint32_t blk_count, lut[256];
+    ck::fast_lut_init(lut, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
-    ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, &blk_count, blockIdx.x, gridDim.x, 0, 1);
+    ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1);
 }
 
 // XXH3-64 of the listed records (the ones canon_global_kernel finished after the batch's own hash pass)
@@ -229,7 +232,8 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 //   C: 1 wave x 40 KiB (4 per CU)                             2-bit up to ~65 kb, byte-mode up to ~19 kb
 //   D: 1 wave x 159 KiB (the whole CU)                        2-bit up to ~260 kb, byte-mode up to ~76 kb
 constexpr int N_TIERS = 4;
-constexpr uint32_t TIER_DW[N_TIERS] = { 1023, 3580, 10236, 40700 };
+constexpr uint32_t TIER_DW[N_TIERS] = { 1023, 3324, 9980, 40444 };     // + 260 dwords of counter and decode table per workgroup
+constexpr uint32_t TIER_EXTRA_DW = 4 + 256;
 constexpr uint32_t TIER_D_DW = TIER_DW[3];
 constexpr int N_CU = 256;
 
@@ -371,8 +375,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
         a.slice_dw = TIER_DW[t];
-        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), (4 * TIER_DW[t] + 4) * 4, c->stream, a);
-        else hipLaunchKernelGGL(canon_kernel<1>, dim3(grid), dim3(64), (TIER_DW[t] + 4) * 4, c->stream, a);
+        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a);
+        else hipLaunchKernelGGL(canon_kernel<1>, dim3(grid), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a);
         nseg = grid;
         seg_cap = spb * seg_cap;
     }
@@ -550,7 +554,7 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = (uint8_t)y[i]; comp[(uint8_t)x[i] + 32] = (uint8_t)(y[i] + 32); }
     CK_HIP(c, hipMemcpy(c->d_comp, comp, 256, hipMemcpyHostToDevice));
     CK_HIP(c, hipFuncSetAttribute((const void*)canon_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((TIER_D_DW + 4) * 4)));
+                                  (int)((TIER_D_DW + TIER_EXTRA_DW) * 4)));
     return CIRCKIT_OK;
 }
 

@@ -124,7 +124,7 @@ struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t* b
 void wave_body(void* p)
 {
     Launch* L = (Launch*)p;
-    ck::canon_wave_loop(L->a, L->lds, L->blk_count, L->block, L->nblocks, L->wib, 4);
+    ck::canon_wave_loop(L->a, L->lds, L->lut, L->blk_count, L->block, L->nblocks, L->wib, 4);
 }
 template <class C>
 void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
