@@ -28,7 +28,7 @@ def t(name, fn):
     for _ in range(5):
         fn(); ctx.synchronize(); ms.append(ctx.last_kernel_ms())
     print("%-28s %.3f ms (min %.3f)" % (name, sum(ms) / len(ms), min(ms)), flush=True)
-t("canonicalize bytes", lambda: ctx.canonicalize_batch_device(d, o, N, out_bytes=out))
+t("canonicalize bytes", lambda: ctx.canonicalize_batch_device(d, o, N, out_bytes=out)) if not os.environ.get("ONLY_LMSR") else None
 t("lmsr bytes (fwd only)", lambda: ctx.lmsr_batch_device(d, o, N, out_bytes=out))
 t("canonicalize index only", lambda: ctx.canonicalize_batch_device(d, o, N, out_index=idx))
 t("lmsr index only", lambda: ctx.lmsr_batch_device(d, o, N, out_index=idx))
