@@ -17,9 +17,9 @@ namespace ck {
 // Geometry of one workgroup: WPB waves, two records per wave per group, NBUF images in the LDS ring (NBUF-1 groups in
 // flight).  A group is 2*WPB consecutive records; its image is 1 KiB per record (1008 B at most + the 16 B alignment
 // slack of the span start), so every wave issues exactly two DMA instructions per group.
-template <int WPB_, int NBUF_>
+template <int WPB_, int NBUF_, int RPW_ = 2>
 struct StreamCfg {
-    static constexpr int WPB = WPB_, RPW = 2, NBUF = NBUF_;
+    static constexpr int WPB = WPB_, RPW = RPW_, NBUF = NBUF_;
     static constexpr uint32_t GROUP = WPB * RPW;                // records per group
     static constexpr uint32_t SPAN = GROUP * 1024;              // bytes of one image
     static constexpr uint32_t BUF_DW = (SPAN + 64) / 4;
@@ -63,7 +63,7 @@ template <class C, bool HASH, bool AUX>
 CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* ring, uint32_t* blk_count, uint32_t block,
                                    uint32_t nblocks)
 {
-    static_assert(C::RPW == 2, "two records per wave per group");
+    static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
     constexpr int D = C::NBUF - 1;                    // groups in flight
     const uint32_t N = (uint32_t)a.n_records, n_groups = (N + C::GROUP - 1) / C::GROUP;
     if (N == 0) return;
@@ -104,7 +104,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         const uint32_t* img = ring + bi * C::BUF_DW;
 #pragma unroll
         for (int k = 0; k < C::RPW; ++k) {
-            const uint64_t off = k ? o1 : o0;
+            const uint64_t off = k ? o1 : o0;                           // (o2 is loaded but unused when RPW == 1)
             const uint32_t n = (uint32_t)(k ? o2 : o1) - (uint32_t)off;
             const uint32_t rec = ra + k;
             bool done = false;

@@ -16,10 +16,10 @@
 #define CK_FAST_WPE 1     // min waves per SIMD the streaming kernel is compiled for
 #endif
 #ifndef CK_STREAM_WPB
-#define CK_STREAM_WPB 4      // waves per workgroup of the staged streaming kernel
+#define CK_STREAM_WPB 16     // waves per workgroup of the staged streaming kernel
 #endif
 #ifndef CK_STREAM_NBUF
-#define CK_STREAM_NBUF 4     // LDS images per workgroup (NBUF-1 groups in flight); 4 x 8 KiB: 4 workgroups per CU
+#define CK_STREAM_NBUF 2     // LDS images per workgroup (NBUF-1 groups in flight); 2 x 16 KiB, two 16-wave workgroups per CU
 #endif
 #ifndef CK_FAST_BPC
 #define CK_FAST_BPC 128   // workgroups launched per CU (4-6 resident; the rest queue: finer dynamic balance)
@@ -75,7 +75,10 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 
 // The streaming kernel with workgroup-staged input (canon_stream.h): a ring of images of record groups per
 // workgroup, the decode table and the deferral counter.
-using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF>;
+#ifndef CK_STREAM_RPW
+#define CK_STREAM_RPW 1      // records per wave per group
+#endif
+using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW>;
 template <bool HASH, bool AUX>
 __global__ __launch_bounds__(StreamC::WPB * 64, CK_FAST_WPE) void canon_stream_kernel(ck::CanonArgs a)
 {

@@ -12,7 +12,7 @@
 namespace ck { namespace emu {
 // A workgroup = NW waves of 64 fibers.  Wave-level collectives rendezvous the 64 fibers of one wave; block_barrier()
 // rendezvous all fibers of the workgroup.  run_wave() is the 1-wave special case.
-constexpr int MAXW = 8;
+constexpr int MAXW = 16;
 struct WaveSync {
     uint64_t buf[2][64];
     int cnt[2];
@@ -140,8 +140,9 @@ void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
 struct StreamVariant { void (*body)(void*); int wpb; uint32_t group, lds_dw; };
 template <class C> constexpr StreamVariant variant() { return StreamVariant{ stream_body<C>, C::WPB, C::GROUP, C::LDS_DW }; }
 const StreamVariant kStream[] = {
-    variant<ck::StreamCfg<4, 4>>(), variant<ck::StreamCfg<8, 3>>(), variant<ck::StreamCfg<4, 2>>(),
+    variant<ck::StreamCfg<16, 2, 1>>(), variant<ck::StreamCfg<8, 3>>(), variant<ck::StreamCfg<4, 2>>(),
     variant<ck::StreamCfg<8, 2>>(), variant<ck::StreamCfg<2, 4>>(), variant<ck::StreamCfg<1, 3>>(),
+    variant<ck::StreamCfg<4, 4, 1>>(), variant<ck::StreamCfg<8, 6, 1>>(), variant<ck::StreamCfg<4, 4>>(),
 };
 }
 
