@@ -79,7 +79,11 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 #define CK_STREAM_RPW 1      // records per wave per group
 #endif
 using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW>;
-template <bool HASH, bool AUX>
+// The build with every output (index / strand / forward-only) needs ~100 SGPRs: at 16 waves per workgroup only one
+// workgroup would fit a CU (measured: 5.1-5.7 ms instead of 3.4-4.0).  It keeps the 4-wave geometry (2 records per
+// wave, four 8 KiB images), where SGPRs only cost a seventh wave per SIMD.
+using StreamCAux = ck::StreamCfg<4, 4, 2>;
+template <class StreamC, bool HASH, bool AUX>
 __global__ __launch_bounds__(StreamC::WPB * 64, CK_FAST_WPE) void canon_stream_kernel(ck::CanonArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW];
@@ -318,7 +322,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs to
     // workgroup b); the one-wave tiers B, C take 4 segments per workgroup each; tier D is the end of the line
-    const uint64_t per_step = StreamC::GROUP;                              // records a workgroup takes per iteration
+    const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
+    const uint64_t per_step = aux ? StreamCAux::GROUP : StreamC::GROUP;    // records a workgroup takes per iteration
     const uint64_t blocks = (n + per_step - 1) / per_step;
     const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
     const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
@@ -359,11 +364,10 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     {
         // three builds of the streaming kernel: canonical bytes only (the headline), + fused XXH3 (uniq), and the
         // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr)
-        const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
         const dim3 grid(G), block(StreamC::WPB * 64);
-        if (aux) hipLaunchKernelGGL((canon_stream_kernel<true, true>), grid, block, 0, c->stream, a);
-        else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<true, false>), grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL((canon_stream_kernel<false, false>), grid, block, 0, c->stream, a);
+        if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux, true, true>), grid, dim3(StreamCAux::WPB * 64), 0, c->stream, a);
+        else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC, true, false>), grid, block, 0, c->stream, a);
+        else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false>), grid, block, 0, c->stream, a);
     }
     unsigned nseg = G;              // segments / capacity of the list the next tier consumes
     uint32_t seg_cap = cap;

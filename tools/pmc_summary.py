@@ -5,6 +5,6 @@ for path in sys.argv[1:]:
     for f in glob.glob(path + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for row in csv.DictReader(open(f)):
-            acc[(row["Kernel_Name"][:60], row["Counter_Name"])].append(float(row["Counter_Value"]))
+            acc[(row["Kernel_Name"][:120], row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (k, c), v in sorted(acc.items()):
-            print("%-62s %-24s n=%-3d avg=%.6g" % (k, c, len(v), sum(v) / len(v)))
+            print("%-122s %-24s n=%-3d avg=%.6g" % (k, c, len(v), sum(v) / len(v)))
