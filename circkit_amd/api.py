@@ -42,6 +42,7 @@ SIGNATURES = {
     "circkit_xxh3_64": (_i, [_vp, _vp, _sz, ctypes.POINTER(_u64)]),
     "circkit_uniq_reset": (_i, [_vp, _u64]),
     "circkit_uniq_insert_device": (_i, [_vp, _vp, _u64, _u64]),
+    "circkit_uniq_insert_pairs_device": (_i, [_vp, _vp, _vp, _u64]),
     "circkit_uniq_lookup_device": (_i, [_vp, _vp, _u64, _vp]),
     "circkit_uniq_first_seen": (_i, [_vp, _vp, _u64, _u64, _vp]),
     "circkit_fasta_parse": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
@@ -179,6 +180,9 @@ class Context:
 
     def uniq_insert_device(self, d_hash, n, base_index=0):
         self._check(self._lib.circkit_uniq_insert_device(self._h, _ptr(d_hash), int(n), int(base_index)))
+
+    def uniq_insert_pairs_device(self, d_hash, d_index, n):
+        self._check(self._lib.circkit_uniq_insert_pairs_device(self._h, _ptr(d_hash), _ptr(d_index), int(n)))
 
     def uniq_lookup_device(self, d_hash, n, d_first_seen):
         self._check(self._lib.circkit_uniq_lookup_device(self._h, _ptr(d_hash), int(n), _ptr(d_first_seen)))

@@ -169,18 +169,20 @@ __global__ void fixed_offsets_kernel(uint64_t base, uint64_t len, uint64_t n, ui
 constexpr uint64_t UNIQ_EMPTY = ~0ull;
 __device__ __forceinline__ uint64_t uniq_slot(uint64_t h, uint64_t mask) { return (h ^ (h >> 29)) & mask; }
 
-__global__ void uniq_insert_kernel(const uint64_t* hash, uint64_t n, uint64_t base, unsigned long long* keys,
+// value of key i: index[i] when given (pairs gathered from other ranks), else base + i (a shard in input order)
+__global__ void uniq_insert_kernel(const uint64_t* hash, const uint64_t* index, uint64_t n, uint64_t base, unsigned long long* keys,
                                    unsigned long long* vals, uint64_t mask, uint32_t* status)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t h = hash[i];
-        if (h == UNIQ_EMPTY) { atomicMin(&vals[mask + 1], (unsigned long long)(base + i)); continue; }
+        const unsigned long long v = index ? index[i] : base + i;
+        if (h == UNIQ_EMPTY) { atomicMin(&vals[mask + 1], v); continue; }
         uint64_t s = uniq_slot(h, mask);
         uint64_t probes = 0;
         for (;;) {
             const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
-            if (old == UNIQ_EMPTY || old == h) { atomicMin(&vals[s], (unsigned long long)(base + i)); break; }
+            if (old == UNIQ_EMPTY || old == h) { atomicMin(&vals[s], v); break; }
             s = (s + 1) & mask;
             if (++probes > mask) { atomicAdd(status, 1u); break; }   // table full
         }
@@ -777,8 +779,8 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
     int rc = ensure_staging(c, 0, n);
     if (rc) return rc;
     CK_HIP(c, hipMemcpyAsync(c->d_hash, hash, n * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_hash, n, base_index, c->d_keys,
-                       c->d_vals, c->uniq_mask, c->d_counters + 4);
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_hash, (const uint64_t*)nullptr, n, base_index,
+                       c->d_keys, c->d_vals, c->uniq_mask, c->d_counters + 4);
     uint64_t* d_fs = (uint64_t*)c->d_off;          // staging reuse: offsets buffer holds >= n + 1 u64
     hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_hash, n, c->d_keys, c->d_vals,
                        c->uniq_mask, d_fs);
@@ -795,7 +797,20 @@ int circkit_uniq_insert_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
     if (!c->d_keys) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, base_index, c->d_keys,
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, (const uint64_t*)nullptr, n, base_index,
+                       c->d_keys, c->d_vals, c->uniq_mask, c->d_counters + 4);
+    CK_HIP(c, hipGetLastError());
+    c->uniq_count += n;
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_insert_pairs_device(circkit_ctx* c, const uint64_t* d_hash, const uint64_t* d_index, uint64_t n)
+{
+    if (!c || (n && (!d_hash || !d_index))) return CIRCKIT_ERR_INVALID_ARG;
+    if (!c->d_keys) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, d_index, n, (uint64_t)0, c->d_keys,
                        c->d_vals, c->uniq_mask, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     c->uniq_count += n;

@@ -127,6 +127,9 @@ int circkit_xxh3_64(circkit_ctx* ctx, const uint8_t* s, size_t n, uint64_t* out_
  *   circkit_uniq_lookup_device   reads the winner for each hash */
 int circkit_uniq_reset(circkit_ctx* ctx, uint64_t expected_keys);
 int circkit_uniq_insert_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t base_index);
+/* the same with an explicit global index per key: the keys a rank receives in the multi-GPU exchange (hash-range
+ * partition, circkit_amd/uniq.py) are a subset of every other rank's shard, not a contiguous range */
+int circkit_uniq_insert_pairs_device(circkit_ctx* ctx, const uint64_t* d_hash, const uint64_t* d_index, uint64_t n);
 int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen);
 
 /* Host-buffer form for streaming hosts (the CLI's batch loop): folds this batch's hashes (global indices

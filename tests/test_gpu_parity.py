@@ -449,3 +449,31 @@ def test_two_contexts_in_two_threads(O):
         t.join()
     assert not errors, errors
     assert results == {"a": True, "b": True}
+
+
+def test_uniq_insert_pairs_device(ctx, O):
+    """circkit_uniq_insert_pairs_device: explicit global indices (what a rank folds in after the hash-range
+    all-to-all); same first-seen answers as inserting the keys in shard order."""
+    import torch
+    rng = np.random.default_rng(12)
+    n = 200_000
+    h = (rng.integers(0, 50_000, size=n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+    h[rng.integers(0, n, 50)] = np.uint64(0xFFFFFFFFFFFFFFFF)        # the table's empty marker is a legal hash value
+    idx = rng.permutation(n).astype(np.int64) + 1000                  # arbitrary, non-contiguous global indices
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_h = torch.from_numpy(h.astype(np.int64)).to(dev)
+    d_i = torch.from_numpy(idx).to(dev)
+    ctx.uniq_reset(n)
+    half = n // 2
+    ctx.uniq_insert_pairs_device(d_h[:half], d_i[:half], half)
+    ctx.uniq_insert_pairs_device(d_h[half:], d_i[half:], n - half)
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    ctx.uniq_lookup_device(d_h, n, out)
+    torch.cuda.synchronize()
+    best = {}
+    for hh, ii in zip(h.tolist(), idx.tolist()):
+        if hh not in best or ii < best[hh]:
+            best[hh] = ii
+    assert out.cpu().numpy().tolist() == [best[x] for x in h.tolist()]
+    ctx.use_own_stream()
