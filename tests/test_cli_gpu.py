@@ -186,3 +186,29 @@ def test_large_output_file_vs_stream_vs_oracle(tmp_path):
         r = subprocess.run([BIN, "canonicalize", str(src)], stdout=f, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode == 0
     assert out.read_bytes() == b">first\nGG\n" + want_c
+
+
+def test_record_longer_than_a_pipeline_chunk(tmp_path):
+    """One 70 Mb record (line-wrapped) between ordinary ones: longer than the CLI's 64 MiB text chunk (the reader
+    grows the chunk) and far beyond the LDS tiers (finished in global scratch) -- mapped-file and stdin input."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    big = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 70_000_000)]
+    lines = big.reshape(-1, 100)
+    wrapped = np.concatenate([lines, np.full((lines.shape[0], 1), 10, dtype=np.uint8)], axis=1).tobytes()
+    small = [bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(30, 1200))).astype(np.uint8)) for _ in range(50)]
+    data = b"".join(b">s%d\n" % i + s + b"\n" for i, s in enumerate(small[:25])) + b">big one\n" + wrapped + \
+        b"".join(b">t%d\n" % i + s + b"\n" for i, s in enumerate(small[25:]))
+    src = tmp_path / "in.fasta"
+    src.write_bytes(data)
+    want = b"".join(b">s%d\n" % i + O.canonicalize(s) + b"\n" for i, s in enumerate(small[:25])) + \
+        b">big one\n" + O.canonicalize(big.tobytes()) + b"\n" + \
+        b"".join(b">t%d\n" % i + O.canonicalize(s) + b"\n" for i, s in enumerate(small[25:]))
+    out = tmp_path / "out.fasta"
+    r = run("canonicalize", str(src), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == want
+    r = subprocess.run([BIN, "uniq", "-c"], input=data, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want                                  # all records distinct: uniq -c prints the same file
