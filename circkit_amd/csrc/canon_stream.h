@@ -1,22 +1,24 @@
 // canon_stream.h -- the streaming kernel with workgroup-staged input.
 //
-// Same per-record routine as canon_fast.h (registers, DPP, fused XXH3); what changes is how record bytes reach
-// the lanes.  Measured on MI355X (tools/microbench/*copy_bench.hip, 10M x 1000 B pure copies): one 16 B/lane
-// request per record per wave at the record's own alignment tops out at 4.4 ms, while flat 16-byte-aligned loads of
-// 8 KiB+ contiguous spans by the whole workgroup reach 3.7-3.9 ms -- the record-per-wave LOADS are what costs
-// bandwidth, the stores are not.  So: a workgroup takes GROUP consecutive records, its four waves DMA the group's
-// byte span into LDS as aligned 16-byte chunks (global_load_lds_dwordx4, two instructions per wave, a ring of
-// three buffers = two groups in flight), and after one barrier every wave pulls its two records out of the LDS
-// image (two ds_read_b128 + a byte funnel by the record's offset mod 16).  Output goes straight from registers to
-// global memory as before.
+// Same per-record routine as canon_fast.h (registers, DPP, fused XXH3); this file is how record bytes reach the
+// lanes.  Measured on MI355X (tools/microbench/*copy_bench.hip, 10M x 1000 B pure copies): one 16 B/lane request per
+// record per wave at the record's own alignment tops out at 4.4 ms, while flat 16-byte-aligned loads of 8 KiB+
+// contiguous spans by the whole workgroup reach 3.7-3.9 ms -- the record-per-wave LOADS are what costs bandwidth,
+// the stores are not.  So: a workgroup takes GROUP consecutive records, its waves DMA the group's byte span into an
+// LDS image as aligned 16-byte chunks (global_load_lds_dwordx4; a ring of NBUF images, NBUF-1 groups in flight), and
+// after one barrier every wave pulls its record(s) out of the image: one aligned ds_read_b128 per lane, pack to
+// 2 bits, and the record's offset mod 16 is removed on the PACKED words (one DPP shift + one 64-bit shift).  Output
+// goes straight from registers to global memory.
+// Default geometry (circkit_hip.hip): 16 waves, one record each, two 16 KiB images -- what matters most is running
+// 32 waves per CU; deeper rings with fewer waves measured slower (Measured).
 #pragma once
 #include "canon_fast.h"
 
 namespace ck {
 
-// Geometry of one workgroup: WPB waves, two records per wave per group, NBUF images in the LDS ring (NBUF-1 groups in
-// flight).  A group is 2*WPB consecutive records; its image is 1 KiB per record (1008 B at most + the 16 B alignment
-// slack of the span start), so every wave issues exactly two DMA instructions per group.
+// Geometry of one workgroup: WPB waves, RPW (1 or 2) records per wave per group, NBUF images in the LDS ring (NBUF-1
+// groups in flight).  A group is RPW*WPB consecutive records; its image is 1 KiB per record (1008 B at most + the
+// 16 B alignment slack of the span start), so every wave issues exactly RPW DMA instructions per group.
 template <int WPB_, int NBUF_, int RPW_ = 2>
 struct StreamCfg {
     static constexpr int WPB = WPB_, RPW = RPW_, NBUF = NBUF_;
