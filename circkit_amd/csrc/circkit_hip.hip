@@ -232,14 +232,12 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS tiers (dwords per wave).  A: 4 waves x 4 KiB per workgroup, 8 workgroups per CU.
-// B: one wave with 40 KiB (4 per CU).  C: one wave with the whole 160 KiB CU.
-// ------------------------------------------------------------------------------------------------
-// LDS tiers of the general kernel (dwords per wave; + 4 dwords per workgroup for the deferral counter).
-//   A: 4 waves x 4 KiB per workgroup (10 workgroups per CU)   2-bit records up to ~6.5 kb
-//   B: 1 wave x 14 KiB (11 per CU)                            2-bit up to ~22 kb: covers BASELINE config 4's 20 kb tail
-//   C: 1 wave x 40 KiB (4 per CU)                             2-bit up to ~65 kb, byte-mode up to ~19 kb
-//   D: 1 wave x 159 KiB (the whole CU)                        2-bit up to ~260 kb, byte-mode up to ~76 kb
+// LDS tiers of the general kernel (dwords per wave; + 260 dwords per workgroup: deferral counter and decode table).
+//   A: 4 waves x 4 KiB per workgroup (9 workgroups per CU)    2-bit records up to ~6.5 kb
+//   B: 1 wave x 13 KiB (11 per CU)                            2-bit up to ~21 kb: covers BASELINE config 4's 20 kb tail
+//   C: 1 wave x 39 KiB (4 per CU)                             2-bit up to ~63 kb, byte-mode up to ~18 kb
+//   D: 1 wave x 158 KiB (the whole CU)                        2-bit up to ~258 kb, byte-mode up to ~76 kb
+//   beyond: canon_global_kernel, the same code over a global-memory scratch (finish_giants)
 constexpr int N_TIERS = 4;
 constexpr uint32_t TIER_DW[N_TIERS] = { 1023, 3324, 9980, 40444 };     // + 260 dwords of counter and decode table per workgroup
 constexpr uint32_t TIER_EXTRA_DW = 4 + 256;
