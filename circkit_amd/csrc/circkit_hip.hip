@@ -234,14 +234,26 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 // ------------------------------------------------------------------------------------------------
 // LDS tiers of the general kernel (dwords per wave; + 260 dwords per workgroup: deferral counter and decode table).
 //   A: 4 waves x 4 KiB per workgroup (9 workgroups per CU)    2-bit records up to ~6.5 kb
-//   B: 1 wave x 13 KiB (11 per CU)                            2-bit up to ~21 kb: covers BASELINE config 4's 20 kb tail
+//   B1: 1 wave x 9 KiB (16 per CU)                            2-bit up to ~14.7 kb
+//   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~21 kb: covers BASELINE config 4's 20 kb tail
 //   C: 1 wave x 39 KiB (4 per CU)                             2-bit up to ~63 kb, byte-mode up to ~18 kb
 //   D: 1 wave x 158 KiB (the whole CU)                        2-bit up to ~258 kb, byte-mode up to ~76 kb
 //   beyond: canon_global_kernel, the same code over a global-memory scratch (finish_giants)
+#ifndef CK_TIER_KEEP
+#define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
+#endif
+#ifndef CK_TIER_B1
+#define CK_TIER_B1 2300
+#endif
+#if CK_TIER_B1 > 0
+constexpr int N_TIERS = 5;
+constexpr uint32_t TIER_DW[N_TIERS] = { 1023, CK_TIER_B1, 3324, 9980, 40444 };     // + 260 dwords of counter and decode table per workgroup
+#else
 constexpr int N_TIERS = 4;
-constexpr uint32_t TIER_DW[N_TIERS] = { 1023, 3324, 9980, 40444 };     // + 260 dwords of counter and decode table per workgroup
+constexpr uint32_t TIER_DW[N_TIERS] = { 1023, 3324, 9980, 40444 };
+#endif
 constexpr uint32_t TIER_EXTRA_DW = 4 + 256;
-constexpr uint32_t TIER_D_DW = TIER_DW[3];
+constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
 constexpr int N_CU = 256;
 
 }  // namespace
@@ -258,7 +270,7 @@ struct circkit_ctx {
     uint8_t* d_comp = nullptr;
     uint32_t* d_counters = nullptr;      // [3] unprocessed records; [4] uniq table overflow
     // segmented deferral lists: streaming kernel -> tier A -> tier B -> tier C (one segment per producing workgroup)
-    uint32_t* d_lists[N_TIERS] = { nullptr, nullptr, nullptr, nullptr };   // input list of tier i (output of the stage before)
+    uint32_t* d_lists[N_TIERS] = {};     // input list of tier i (output of the stage before)
     uint32_t* d_seg_counts = nullptr;    // [N_TIERS * seg_alloc]
     uint64_t list_cap = 0, seg_alloc = 0;
     // host-batch staging (grow only)
@@ -373,7 +385,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     uint32_t seg_cap = cap;
     for (int t = 0; t < N_TIERS; ++t) {
         const bool last = t == N_TIERS - 1;
-        const unsigned spb = t == 0 ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
+        const unsigned spb = t <= CK_TIER_KEEP ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
         const unsigned grid = (nseg + spb - 1) / spb;
         a.list = c->d_lists[t]; a.list_count = c->d_seg_counts + (uint64_t)t * c->seg_alloc;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb;
