@@ -17,18 +17,32 @@
 namespace ck {
 
 // Geometry of one workgroup: WPB waves, RPW (1 or 2) records per wave per group, NBUF images in the LDS ring (NBUF-1
-// groups in flight).  A group is RPW*WPB consecutive records; its image is 1 KiB per record (1008 B at most + the
-// 16 B alignment slack of the span start), so every wave issues exactly RPW DMA instructions per group.
-template <int WPB_, int NBUF_, int RPW_ = 2>
+// groups in flight).  A group is RPW*WPB consecutive records; its image is ROWS KiB per record (1008 / 2032 B at most
+// + the 16 B alignment slack of the span start), so every wave issues ROWS*RPW DMA instructions per group.  The
+// ROWS == 2 build also takes records of 1009..2032 bases (fast_canon2, two packed words per lane); it is a separate
+// build because carrying that path costs the one-word path ~12 % more instructions (measured), so launch_canon picks
+// it only for batches whose mean record length lies in that range.
+template <int WPB_, int NBUF_, int RPW_ = 2, int ROWS_ = 1>
 struct StreamCfg {
     static constexpr int WPB = WPB_, RPW = RPW_, NBUF = NBUF_;
+    static constexpr int ROWS = ROWS_;                          // packed words per lane a record may take: 1 (<= 1008 b) or 2 (<= 2032 b)
     static constexpr uint32_t GROUP = WPB * RPW;                // records per group
-    static constexpr uint32_t SPAN = GROUP * 1024;              // bytes of one image
+    static constexpr int DPW = ROWS * RPW;                      // DMA instructions (1 KiB each) per wave per group
+    static constexpr uint32_t SPAN = GROUP * 1024 * ROWS;       // bytes of one image: ROWS KiB per record (incl. alignment slack)
     static constexpr uint32_t BUF_DW = (SPAN + 64) / 4;
-    // ring, then the decode table and the deferral counter: a record's lanes past its end read up to 63 chunks
-    // beyond the image (never used), which for the last buffer lands in the table -- keep it behind the ring
-    static constexpr uint32_t LDS_DW = NBUF * BUF_DW + 256 + 4;
+    // ring, then the decode table, the deferral counter and (ROWS == 2) 1 KiB of padding: a record's lanes past its
+    // end read up to 63 / 127 chunks beyond the image (never used), which for the last buffer lands in the table and
+    // the padding
+    static constexpr uint32_t LDS_DW = NBUF * BUF_DW + 256 + 4 + (ROWS == 2 ? 256 : 0);
 };
+
+// 1 KiB slot of the image that DMA instruction i of wave w fills: the first RPW instructions of every wave tile the
+// first half of the image, the rest the second half
+template <class C>
+CK_DEV uint32_t stream_slot(uint32_t w, uint32_t i)
+{
+    return i < (uint32_t)C::RPW ? w * C::RPW + i : C::GROUP + w * C::RPW + (i - C::RPW);     // (second half: ROWS == 2 only)
+}
 
 struct StreamGroup {
     uint32_t base_lo;   // low 32 bits of the byte offset (into a.bytes) of the image's first byte
@@ -40,7 +54,7 @@ struct StreamGroup {
 // -- the vmcnt bookkeeping of the loop depends on it.  Lanes past the span re-fetch its last chunk; unstaged groups
 // fetch the offsets array (always readable).  All but the per-lane clamp is scalar work.
 template <class C>
-CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, uint64_t e, uint32_t* buf, const uint32_t (&c16)[C::RPW])
+CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, uint64_t e, uint32_t* buf, const uint32_t (&c16)[C::DPW])
 {
     static_assert((C::SPAN & (C::SPAN - 1)) == 0, "image size must be a power of two");
     const uint32_t mis = ((uint32_t)(uintptr_t)a.bytes + (uint32_t)s) & 15;
@@ -53,10 +67,16 @@ CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, u
     grp.ok = in_range && ((s >> 4) != 0 || (uint32_t)s >= mis) && nb1 / C::SPAN == 0;
     const uint32_t last16 = grp.ok ? (uint32_t)nb1 & ~15u : 0u;
     const uint8_t* src = grp.ok ? a.bytes + base : (const uint8_t*)a.offsets;
+    // DMA i of wave w covers chunks (i*WPB*RPW + w*RPW + i%RPW...) -- laid out so that the first RPW instructions of all
+    // waves together cover the first half of the image: groups of records up to 1 KiB (the common case) need only
+    // those, and the second half is skipped.  Allowed because with one group in flight (NBUF == 2) no vmcnt wait
+    // counts DMA instructions; deeper rings always issue all of them.
     const uint32_t w = wave_in_block();
+    const bool second_half = C::ROWS == 2 && (C::NBUF > 2 || last16 >= C::SPAN / 2);
 #pragma unroll
-    for (uint32_t i = 0; i < (uint32_t)C::RPW; ++i)
-        glds16_async_s(buf + (w * C::RPW + i) * 256, src, c16[i] < last16 ? c16[i] : last16);
+    for (uint32_t i = 0; i < (uint32_t)C::DPW; ++i)
+        if (i < (uint32_t)C::RPW || second_half)
+            glds16_async_s(buf + stream_slot<C>(w, i) * 256, src, c16[i] < last16 ? c16[i] : last16);
     return grp;
 }
 
@@ -80,9 +100,9 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     if (HASH) hc = fast_hash_const();
     FastShape shape;
     const bool stores = a.out_bytes || a.out_hash || a.out_index || a.out_strand;     // else only deferrals store
-    uint32_t c16[C::RPW];
+    uint32_t c16[C::DPW];
 #pragma unroll
-    for (int i = 0; i < C::RPW; ++i) c16[i] = ((w * C::RPW + i) * 64 + t) * 16;
+    for (int i = 0; i < C::DPW; ++i) c16[i] = (stream_slot<C>(w, (uint32_t)i) * 64 + t) * 16;
     // ring state in scalars: q[0] = the group being processed, q[1..D-1] = the ones in flight behind it
     StreamGroup q[D];
 #pragma unroll
@@ -92,7 +112,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         sload_2u64(a.offsets + (uint64_t)gg * C::GROUP, a.offsets + (uint64_t)gg * C::GROUP + C::GROUP, s, e);
         q[d] = stream_issue<C>(a, g < n_staged, s, e, ring + d * C::BUF_DW, c16);
     }
-    vmem_wait<(D - 1) * C::RPW>();                    // the first group's DMAs; the later ones may still fly
+    vmem_wait<(D - 1) * C::DPW>();                    // the first group's DMAs; the later ones may still fly
     block_barrier();
     uint32_t bi = 0, it = 0;                          // buffer index of q[0]; iteration count
     for (uint32_t g = block; g < n_staged; g += nblocks, ++it) {
@@ -110,7 +130,17 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
             const uint32_t n = (uint32_t)(k ? o2 : o1) - (uint32_t)off;
             const uint32_t rec = ra + k;
             bool done = false;
-            if (q[0].ok && fast_eligible(n)) {
+            if (C::ROWS == 2 && q[0].ok && fast2_eligible(n)) {
+                // 1009..2032 bases: two chunks per lane (c0 + 2t, c0 + 2t + 1); the word behind them is lane t+1's first
+                const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;     // <= 128
+                const uint32_t* cp = img + 4 * ((rel >> 4) + 2 * t);
+                uint32_t m0, m1;
+                const uint32_t P0 = fast_pack(lds_load16(cp), m0), P1 = fast_pack(lds_load16(cp + 4), m1);
+                const uint64_t bad0 = ballot(m0 != 0) & (~0ull >> (64 - ((nch + 1) >> 1)));       // chunk 2t   < nch
+                const uint64_t bad1 = ballot(m1 != 0) & ((nch >> 1) >= 64 ? ~0ull : (1ull << (nch >> 1)) - 1);   // chunk 2t+1 < nch
+                const uint32_t sh2 = 32 - 2 * a16;
+                done = fast_canon2<AUX>(a, lut, rec, off, n, lshr64(P0, P1, sh2), lshr64(P1, wave_shl1(P0), sh2), (bad0 | bad1) != 0);
+            } else if (q[0].ok && fast_eligible(n)) {
                 // lane t packs the aligned chunk c0 + t of the image; the record starts a16 bytes into chunk c0, so
                 // the byte funnel is done on the packed words: 2*a16 bits, with the next lane's word behind
                 const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;
@@ -124,13 +154,12 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
             if (!done) defer_record(a, blk_count, block, rec);
         }
         // the next group's DMAs (issued D-1 iterations ago) must have landed.  Younger vector-memory instructions:
-        // the DMAs of the D-1 groups issued since, and the stores of this and the D-1 previous iterations (>= RPW
-        // each: every record stores its bytes, hash or index, or its deferral).  While the next group is still one
-        // of the prologue's (it + 1 < D) there are fewer: the prologue's later DMAs, the DMAs and stores of the
-        // iterations so far -- (D + it) * RPW, of which D * RPW is counted on.
-        if (!stores) vmem_wait<(D - 1) * C::RPW>();
-        else if (it + 1 < (uint32_t)D) vmem_wait<D * C::RPW>();
-        else vmem_wait<(2 * D - 1) * C::RPW>();
+        // the DMAs of the D-1 groups issued since (DPW each), and the stores of this and the D-1 previous iterations
+        // (>= RPW each: every record stores its bytes, hash or index, or its deferral).  While the next group is still
+        // one of the prologue's (it + 1 < D) there are fewer stores: only this iteration's are counted on.
+        if (!stores) vmem_wait<(D - 1) * C::DPW>();
+        else if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + C::RPW>();
+        else vmem_wait<(D - 1) * C::DPW + D * C::RPW>();
         block_barrier();
 #pragma unroll
         for (int d = 0; d + 1 < D; ++d) q[d] = q[d + 1];

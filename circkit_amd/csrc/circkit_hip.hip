@@ -13,13 +13,13 @@
 #include "canon_fast.h"
 #include "canon_stream.h"
 #ifndef CK_FAST_WPE
-#define CK_FAST_WPE 1     // min waves per SIMD the streaming kernel is compiled for
+#define CK_FAST_WPE 8     // min waves per SIMD the streaming kernel is compiled for (two 16-wave workgroups per CU: <= 64 VGPRs)
 #endif
 #ifndef CK_STREAM_WPB
 #define CK_STREAM_WPB 16     // waves per workgroup of the staged streaming kernel
 #endif
 #ifndef CK_STREAM_NBUF
-#define CK_STREAM_NBUF 2     // LDS images per workgroup (NBUF-1 groups in flight); 2 x 16 KiB, two 16-wave workgroups per CU
+#define CK_STREAM_NBUF 2     // LDS images per workgroup (NBUF-1 groups in flight); 2 x 32 KiB, two 16-wave workgroups per CU
 #endif
 #ifndef CK_FAST_BPC
 #define CK_FAST_BPC 128   // workgroups launched per CU (4-6 resident; the rest queue: finer dynamic balance)
@@ -78,14 +78,30 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 #ifndef CK_STREAM_RPW
 #define CK_STREAM_RPW 1      // records per wave per group
 #endif
-using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW>;
+// Two builds of every streaming kernel: ROWS = 1 takes records of 48..1008 bases (one packed word per lane), ROWS = 2
+// also 1009..2032 (two words per lane, 2 KiB of image per record); the batch's mean record length decides.  Carrying
+// the two-word path makes the one-word path ~12 % longer, hence two builds.  Who decides: the host when it has the
+// offsets (host-buffer API) or remembers the answer for this offsets array; otherwise stream_mode_kernel on the
+// device, with BOTH builds launched (the idle one's workgroups return at once, ~40 us) so that the call stays
+// asynchronous -- the answer is copied back and remembered for the next batch with the same offsets array.
+using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
+using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
 // The build with every output (index / strand / forward-only) needs ~100 SGPRs: at 16 waves per workgroup only one
-// workgroup would fit a CU (measured: 5.1-5.7 ms instead of 3.4-4.0).  It keeps the 4-wave geometry (2 records per
-// wave, four 8 KiB images), where SGPRs only cost a seventh wave per SIMD.
-using StreamCAux = ck::StreamCfg<4, 4, 2>;
-template <class StreamC, bool HASH, bool AUX>
-__global__ __launch_bounds__(StreamC::WPB * 64, CK_FAST_WPE) void canon_stream_kernel(ck::CanonArgs a)
+// workgroup would fit a CU (measured: 5.1-5.7 ms instead of 3.4-4.0).  It keeps 4-wave workgroups (2 records per
+// wave), where SGPRs only cost a seventh wave per SIMD.
+using StreamCAux = ck::StreamCfg<4, 4, 2, 1>;
+using StreamCAux2 = ck::StreamCfg<4, 2, 2, 2>;
+
+__global__ void stream_mode_kernel(const uint64_t* offsets, uint64_t n, uint32_t* mode)
 {
+    const uint64_t mean = n ? (offsets[n] - offsets[0]) / n : 0;
+    *mode = mean > ck::FAST_MAX_N && mean <= ck::FAST2_MAX_N ? 2u : 1u;
+}
+
+template <class StreamC, bool HASH, bool AUX>
+__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* mode)
+{
+    if (mode && *mode != (uint32_t)StreamC::ROWS) return;    // the other build has this batch (mode == nullptr: the host chose)
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + 256;
@@ -284,6 +300,12 @@ struct circkit_ctx {
     uint64_t* last_hash = nullptr;
     unsigned giant_nseg = 0; uint32_t giant_seg_cap = 0;
     bool giants_pending = false;
+    // which build of the streaming kernel took the batch with this offsets array (0 = not known yet)
+    const void* mode_key = nullptr; uint64_t mode_key_n = 0;
+    uint32_t* h_mode = nullptr;          // pinned; written by the device-side decision's copy-back
+    hipEvent_t mode_ev = nullptr;
+    bool mode_pending = false;
+    uint32_t mode_known = 0;
     // uniq table
     unsigned long long *d_keys = nullptr, *d_vals = nullptr;
     uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
@@ -327,7 +349,7 @@ int ensure_lists(circkit_ctx* c, uint64_t entries, uint64_t segs)
 }
 
 int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out,
-                 uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags)
+                 uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags, uint32_t host_mode = 0)
 {
     if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
     CK_HIP(c, hipSetDevice(c->device));
@@ -376,10 +398,34 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     {
         // three builds of the streaming kernel: canonical bytes only (the headline), + fused XXH3 (uniq), and the
         // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr)
-        const dim3 grid(G), block(StreamC::WPB * 64);
-        if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux, true, true>), grid, dim3(StreamCAux::WPB * 64), 0, c->stream, a);
-        else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC, true, false>), grid, block, 0, c->stream, a);
-        else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false>), grid, block, 0, c->stream, a);
+        const dim3 grid(G), block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64);
+        // which build: 1 / 2 when the host knows, 0 = decided on the device (both launched)
+        uint32_t rows = host_mode;
+        if (!rows) {
+            if (c->mode_pending && c->mode_key == (const void*)d_offsets && c->mode_key_n == n) {
+                if (hipEventQuery(c->mode_ev) == hipSuccess) { c->mode_known = *c->h_mode; c->mode_pending = false; }
+                else (void)hipGetLastError();          // hipErrorNotReady is not an error of this call
+            }
+            if (c->mode_key == (const void*)d_offsets && c->mode_key_n == n && !c->mode_pending) rows = c->mode_known;
+        }
+        const uint32_t* mode = nullptr;
+        if (!rows) {
+            mode = c->d_counters + 5;
+            hipLaunchKernelGGL(stream_mode_kernel, dim3(1), dim3(1), 0, c->stream, d_offsets, n, c->d_counters + 5);
+            CK_HIP(c, hipMemcpyAsync(c->h_mode, c->d_counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
+            CK_HIP(c, hipEventRecord(c->mode_ev, c->stream));
+            c->mode_key = d_offsets; c->mode_key_n = n; c->mode_pending = true; c->mode_known = 0;
+        }
+        if (rows != 2) {
+            if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux, true, true>), grid, block_aux, 0, c->stream, a, mode);
+            else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC, true, false>), grid, block, 0, c->stream, a, mode);
+            else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false>), grid, block, 0, c->stream, a, mode);
+        }
+        if (rows != 1) {
+            if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux2, true, true>), grid, block_aux, 0, c->stream, a, mode);
+            else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC2, true, false>), grid, block, 0, c->stream, a, mode);
+            else hipLaunchKernelGGL((canon_stream_kernel<StreamC2, false, false>), grid, block, 0, c->stream, a, mode);
+        }
     }
     unsigned nseg = G;              // segments / capacity of the list the next tier consumes
     uint32_t seg_cap = cap;
@@ -523,8 +569,10 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     if (total) CK_HIP(c, hipMemcpyAsync(c->d_in, bytes, total, hipMemcpyHostToDevice, c->stream));
     CK_HIP(c, hipMemcpyAsync(c->d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     const bool need_bytes = out || hash;
+    const uint64_t mean = total / n;                  // the host has the offsets: it picks the streaming kernel's build
     rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
-                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags);
+                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags,
+                      mean > ck::FAST_MAX_N && mean <= ck::FAST2_MAX_N ? 2u : 1u);
     if (rc) return rc;
     if ((rc = finish_giants(c))) return rc;
     if (out && total) CK_HIP(c, hipMemcpyAsync(out, c->d_out, total, hipMemcpyDeviceToHost, c->stream));
@@ -563,6 +611,9 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     c->stream = c->own_stream;
     CK_HIP(c, hipEventCreate(&c->ev0));
     CK_HIP(c, hipEventCreate(&c->ev1));
+    CK_HIP(c, hipEventCreateWithFlags(&c->mode_ev, hipEventDisableTiming));
+    CK_HIP(c, hipHostMalloc((void**)&c->h_mode, 64, hipHostMallocDefault));
+    *c->h_mode = 0;
     CK_HIP(c, hipMalloc(&c->d_comp, 256));
     CK_HIP(c, hipMalloc(&c->d_counters, 8 * sizeof(uint32_t)));
     CK_HIP(c, hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
@@ -587,6 +638,8 @@ int circkit_ctx_destroy(circkit_ctx* c)
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->mode_ev) (void)hipEventDestroy(c->mode_ev);
+    if (c->h_mode) (void)hipHostFree(c->h_mode);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return CIRCKIT_OK;

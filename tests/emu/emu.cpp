@@ -143,6 +143,8 @@ const StreamVariant kStream[] = {
     variant<ck::StreamCfg<16, 2, 1>>(), variant<ck::StreamCfg<8, 3>>(), variant<ck::StreamCfg<4, 2>>(),
     variant<ck::StreamCfg<8, 2>>(), variant<ck::StreamCfg<2, 4>>(), variant<ck::StreamCfg<1, 3>>(),
     variant<ck::StreamCfg<4, 4, 1>>(), variant<ck::StreamCfg<8, 6, 1>>(), variant<ck::StreamCfg<4, 4>>(),
+    // ROWS = 2: records of up to 2032 bases, two packed words per lane
+    variant<ck::StreamCfg<16, 2, 1, 2>>(), variant<ck::StreamCfg<4, 2, 2, 2>>(), variant<ck::StreamCfg<8, 3, 1, 2>>(),
 };
 }
 

@@ -87,7 +87,7 @@ def test_streaming_kernel_takes_the_headline_records():
     seqs = seqsets.random_mixed(35, 64, 1000, 1000)
     data, offs = seqsets.pack(seqs)
     for k, (wpb, rpw, _) in emu.STAGED_GEOMETRIES.items():
-        emu.canonicalize_batch(data, offs, staged=k)
+        emu.canonicalize_batch(data, offs, staged=k, slice_dw=4096)
         last_group = len(seqs) - (len(seqs) - 1) // (wpb * rpw) * (wpb * rpw)
         assert emu.last_fast_count == len(seqs) - last_group     # the batch's last group is left to the general kernel
     for staged in (1, 2):
@@ -157,3 +157,18 @@ def test_staged_kernel_unaligned_payload_and_nonzero_first_offset():
                 a, b = int(offs[i]), int(offs[i + 1])
                 assert out[a:b].tobytes() == want[i], (shift, lead, i, len(s))
                 assert int(h[i]) == O.xxh3_64(want[i])
+
+
+def test_two_words_per_lane_records_take_the_streaming_kernel():
+    """Pure-ACGT records of 1009..2032 bases (two packed words per lane) stay in the streaming kernel; 2033 and beyond,
+    and 1009+ with N, go to the general kernel; results equal the oracle either way."""
+    seqs = seqsets.random_mixed(970, 40, 1009, 2032) + seqsets.random_mixed(971, 8, 2032, 2032) + seqsets.random_mixed(972, 8, 1009, 1009)
+    for k in emu.TWO_ROW:
+        check(seqs, staged=k)
+        wpb, rpw, _ = emu.STAGED_GEOMETRIES[k]
+        assert emu.last_fast_count == len(seqs) - ((len(seqs) - 1) % (wpb * rpw) + 1)      # all but the batch's last group
+    check(seqs, staged=1, slice_dw=4096)
+    assert emu.last_fast_count == 0                                                        # the one-word build leaves them
+    seqs = seqsets.random_mixed(973, 20, 2033, 2100) + seqsets.random_mixed(974, 12, 1009, 2032, b"ACGTN")
+    check(seqs, staged=emu.TWO_ROW[0], slice_dw=4096)
+    assert emu.last_fast_count == 0

@@ -477,3 +477,42 @@ def test_uniq_insert_pairs_device(ctx, O):
             best[hh] = ii
     assert out.cpu().numpy().tolist() == [best[x] for x in h.tolist()]
     ctx.use_own_stream()
+
+
+def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
+    """The ROWS == 2 build of the streaming kernel (records up to 2032 bases, two packed words per lane): chosen by the
+    batch's mean length -- by the host for host buffers, on the device for device buffers (first call: both builds are
+    launched; later calls with the same offsets array: the remembered one)."""
+    import torch
+    from tests import seqsets
+    seqs = seqsets.random_mixed(101, 600, 1009, 2032) + seqsets.random_mixed(102, 60, 1009, 2032, b"ACGTN") + \
+        seqsets.random_mixed(103, 100, 48, 1008) + seqsets.random_mixed(104, 30, 2033, 2600) + \
+        [b"ACGT" * 400, b"A" * 1500, seqsets.random_mixed(105, 1, 1164, 1164)[0] * 1]
+    _check(ctx, O, seqs)                                            # host API, every output
+    data, offs = seqsets.pack(seqs)
+    n = len(seqs)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
+    for rep in range(3):                                            # 1st: device decides; 2nd / 3rd: remembered
+        d_out = torch.zeros_like(d_bytes)
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep else None)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), exp), rep
+        if rep:
+            assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    ctx.use_own_stream()
+
+
+def test_randomized_rare_paths_long_profile():
+    """tools/gpu_fuzz.py with most records in 1009..2032 bases."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "78", "100000", "long"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout

@@ -2,7 +2,8 @@
 index builds on a subsample).  Mixtures aimed at the streaming kernel's rare paths: planted duplicate minimal
 16-mers, tandem repeats, reverse-complement palindromes (equal minimal keys on both strands), records around the
 48 / 240 / 1008 limits, N / '-' sprinkled in, lengths 0..1300.
-usage: python tools/gpu_fuzz.py [seed] [records]"""
+usage: python tools/gpu_fuzz.py [seed] [records] [profile]   (profile "long": most records 1009..2032 bases -- the
+two-words-per-lane build of the streaming kernel)"""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ from tests import seqsets
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000
+profile = sys.argv[3] if len(sys.argv) > 3 else "short"
 rng = np.random.default_rng(seed)
 LUT = np.frombuffer(b"ACGT", dtype=np.uint8)
 COMP = np.zeros(256, dtype=np.uint8)
@@ -31,7 +33,9 @@ seqs = []
 t0 = time.time()
 for i in range(count):
     k = rng.integers(0, 100)
-    if k < 30: L = 1000
+    if profile == "long" and k < 85:
+        L = int(rng.integers(1009, 2033)) if k < 60 else int(rng.choice([1009, 1010, 1023, 1024, 1025, 1039, 1040, 1041, 1164, 1500, 1679, 2015, 2016, 2017, 2031, 2032, 2033, 2047, 2048, 2049]))
+    elif k < 30: L = 1000
     elif k < 60: L = int(rng.integers(48, 1009))
     elif k < 70: L = int(rng.choice([0, 1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 239, 240, 241, 242, 255, 256, 257,
                                       991, 992, 993, 1006, 1007, 1008, 1009, 1010, 1023, 1024, 1025]))
