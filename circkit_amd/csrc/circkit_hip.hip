@@ -79,7 +79,8 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 #define CK_STREAM_RPW 1      // records per wave per group
 #endif
 // Two builds of every streaming kernel: ROWS = 1 takes records of 48..1008 bases (one packed word per lane), ROWS = 2
-// also 1009..2032 (two words per lane, 2 KiB of image per record); the batch's mean record length decides.  Carrying
+// also 1009..2032 (two words per lane, 2 KiB of image per record); it is used when at least one record in four is
+// such a record.  Carrying
 // the two-word path makes the one-word path ~12 % longer, hence two builds.  Who decides: the host when it has the
 // offsets (host-buffer API) or remembers the answer for this offsets array; otherwise stream_mode_kernel on the
 // device, with BOTH builds launched (the idle one's workgroups return at once, ~40 us) so that the call stays
@@ -92,10 +93,22 @@ using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
 using StreamCAux = ck::StreamCfg<4, 4, 2, 1>;
 using StreamCAux2 = ck::StreamCfg<4, 2, 2, 2>;
 
-__global__ void stream_mode_kernel(const uint64_t* offsets, uint64_t n, uint32_t* mode)
+// The ROWS = 2 build is used when at least 1 record in 4 is a 1009..2032-base one (it runs the shorter records 4-6 %
+// slower, the longer ones 1.5x faster than LDS tier A; at 15 % -- BASELINE config 4 -- it measured 2 % slower overall).
+// count[0] must be 0 on entry.
+__global__ __launch_bounds__(256) void stream_count_kernel(const uint64_t* offsets, uint64_t n, uint32_t* count)
 {
-    const uint64_t mean = n ? (offsets[n] - offsets[0]) / n : 0;
-    *mode = mean > ck::FAST_MAX_N && mean <= ck::FAST2_MAX_N ? 2u : 1u;
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t len = offsets[i + 1] - offsets[i];
+        mine += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
+    }
+    const uint64_t total = ck::wave_sum_u64(mine);
+    if (ck::lane_id() == 0 && total) atomicAdd(count, (uint32_t)total);
+}
+__global__ void stream_mode_kernel(const uint32_t* count, uint64_t n, uint32_t* mode)
+{
+    *mode = (uint64_t)count[0] * 4 >= n && count[0] ? 2u : 1u;
 }
 
 template <class StreamC, bool HASH, bool AUX>
@@ -411,7 +424,9 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const uint32_t* mode = nullptr;
         if (!rows) {
             mode = c->d_counters + 5;
-            hipLaunchKernelGGL(stream_mode_kernel, dim3(1), dim3(1), 0, c->stream, d_offsets, n, c->d_counters + 5);
+            CK_HIP(c, hipMemsetAsync(c->d_counters + 6, 0, 4, c->stream));
+            hipLaunchKernelGGL(stream_count_kernel, dim3(N_CU), dim3(256), 0, c->stream, d_offsets, n, c->d_counters + 6);
+            hipLaunchKernelGGL(stream_mode_kernel, dim3(1), dim3(1), 0, c->stream, (const uint32_t*)(c->d_counters + 6), n, c->d_counters + 5);
             CK_HIP(c, hipMemcpyAsync(c->h_mode, c->d_counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
             CK_HIP(c, hipEventRecord(c->mode_ev, c->stream));
             c->mode_key = d_offsets; c->mode_key_n = n; c->mode_pending = true; c->mode_known = 0;
@@ -569,10 +584,10 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     if (total) CK_HIP(c, hipMemcpyAsync(c->d_in, bytes, total, hipMemcpyHostToDevice, c->stream));
     CK_HIP(c, hipMemcpyAsync(c->d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     const bool need_bytes = out || hash;
-    const uint64_t mean = total / n;                  // the host has the offsets: it picks the streaming kernel's build
+    uint64_t two_word = 0;                            // the host has the offsets: it picks the streaming kernel's build
+    for (uint64_t i = 0; i < n; ++i) { const uint64_t len = offsets[i + 1] - offsets[i]; two_word += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N; }
     rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
-                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags,
-                      mean > ck::FAST_MAX_N && mean <= ck::FAST2_MAX_N ? 2u : 1u);
+                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags, two_word * 4 >= n && two_word ? 2u : 1u);
     if (rc) return rc;
     if ((rc = finish_giants(c))) return rc;
     if (out && total) CK_HIP(c, hipMemcpyAsync(out, c->d_out, total, hipMemcpyDeviceToHost, c->stream));
