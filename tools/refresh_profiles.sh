@@ -7,7 +7,7 @@ mkdir -p $O
 cd $R
 tools/pmc_run.sh refresh_pmc > /dev/null
 cp gpurun_out/refresh_pmc.summary.txt $O/r01_pmc_counters.txt
-python tools/make_traffic.py $O/r01_pmc_counters.txt "StreamCfg<16, 2, 1>, false, false" $O/traffic.json > /dev/null
+python tools/make_traffic.py $O/r01_pmc_counters.txt "StreamCfg<16, 2, 1, 1>, false, false" $O/traffic.json > /dev/null
 cp $O/traffic.json profiles/traffic.json        # so that the bench line below carries the fresh figure
 tools/prof_run.sh refresh_stats > /dev/null
 cp gpurun_out/refresh_stats_kernel_stats.csv $O/r01_kernel_stats.csv
