@@ -168,4 +168,40 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Rescue pass: eligible records that the staged loop could not take because their GROUP was not staged -- one long
+// record is enough to push a group's span past its image, so in batches of mixed lengths most short records end up
+// here -- are run through the same register routine, fetched straight from memory: 16 bytes per lane at the record's
+// own alignment (lanes past the last full word re-read the record's LAST 16 bytes, in bounds, and shift their tail
+// symbols up).  One wave per record of the streaming kernel's deferral list; what is still not eligible (other
+// alphabets, ties, longer records) goes on to the LDS tiers.  A separate kernel on purpose: the same fallback inside
+// the staged loop cost the staged path 5 %.
+template <bool HASH, bool AUX>
+struct RescueState {        // per-wave constants of the rescue pass (kept across list segments)
+    FastHashConst hc{};
+    FastShape shape;
+};
+// one wave's share of list segment `seg_index`; failures are appended to the SAME segment index of the output list
+template <bool HASH, bool AUX>
+CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, RescueState<HASH, AUX>& st, uint32_t* seg_count, uint32_t seg_index,
+                                 uint32_t wib, uint32_t wpb)
+{
+    const uint32_t t = lane_id();
+    const uint32_t count = a.list_count[seg_index];
+    const uint32_t* seg = a.list + (uint64_t)seg_index * a.in_seg_cap;
+    for (uint32_t i = wib; i < count; i += wpb) {
+        const uint32_t rec = seg[i];
+        const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
+        bool done = false;
+        if (len <= FAST_MAX_N && fast_eligible((uint32_t)len)) {
+            const uint32_t n = (uint32_t)len, nwf = n >> 4;
+            uint32_t miss;
+            uint32_t F = fast_pack(load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t)), miss);
+            F <<= t >= nwf ? ((16 - (n & 15)) & 15) * 2 : 0;
+            done = fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F, ballot(miss != 0));
+        }
+        if (!done) defer_record(a, seg_count, seg_index, rec);
+    }
+}
+
 }  // namespace ck

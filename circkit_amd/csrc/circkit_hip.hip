@@ -106,6 +106,27 @@ __global__ __launch_bounds__(256) void stream_count_kernel(const uint64_t* offse
     const uint64_t total = ck::wave_sum_u64(mine);
     if (ck::lane_id() == 0 && total) atomicAdd(count, (uint32_t)total);
 }
+// Rescue pass (canon_stream.h): the streaming kernel's leftovers that are eligible by themselves, one wave per record.
+// A small persistent grid walks the list segments (a batch the streaming kernel handled completely leaves them
+// empty: the pass then costs a microsecond, not the dispatch of one workgroup per segment); segment s of the input
+// list yields segment s of the output list, so the tiers behind keep their geometry.
+template <bool HASH, bool AUX>
+__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a)
+{
+    __shared__ uint32_t lut[256], seg_count;
+    ck::fast_lut_init(lut, threadIdx.x, 256);
+    ck::RescueState<HASH, AUX> st;
+    if (HASH) st.hc = ck::fast_hash_const();
+    const uint32_t wib = ck::uniform(threadIdx.x >> 6);
+    for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
+        if (threadIdx.x == 0) seg_count = 0;
+        __syncthreads();
+        ck::canon_rescue_segment<HASH, AUX>(a, lut, st, &seg_count, sgm, wib, 4);
+        __syncthreads();
+        if (threadIdx.x == 0) a.defer_count[sgm] = seg_count;
+    }
+}
+
 __global__ void stream_mode_kernel(const uint32_t* count, uint64_t n, uint32_t* mode)
 {
     *mode = (uint64_t)count[0] * 4 >= n && count[0] ? 2u : 1u;
@@ -268,6 +289,9 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 //   C: 1 wave x 39 KiB (4 per CU)                             2-bit up to ~63 kb, byte-mode up to ~18 kb
 //   D: 1 wave x 158 KiB (the whole CU)                        2-bit up to ~258 kb, byte-mode up to ~76 kb
 //   beyond: canon_global_kernel, the same code over a global-memory scratch (finish_giants)
+#ifndef CK_RESCUE_BPC
+#define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
+#endif
 #ifndef CK_TIER_KEEP
 #define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
 #endif
@@ -299,8 +323,8 @@ struct circkit_ctx {
     uint8_t* d_comp = nullptr;
     uint32_t* d_counters = nullptr;      // [3] unprocessed records; [4] uniq table overflow
     // segmented deferral lists: streaming kernel -> tier A -> tier B -> tier C (one segment per producing workgroup)
-    uint32_t* d_lists[N_TIERS] = {};     // input list of tier i (output of the stage before)
-    uint32_t* d_seg_counts = nullptr;    // [N_TIERS * seg_alloc]
+    uint32_t* d_lists[N_TIERS + 1] = {}; // [0] streaming kernel -> rescue pass, [i + 1] input list of tier i (output of the stage before)
+    uint32_t* d_seg_counts = nullptr;    // [(N_TIERS + 1) * seg_alloc]
     uint64_t list_cap = 0, seg_alloc = 0;
     // host-batch staging (grow only)
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_strand = nullptr;
@@ -346,7 +370,7 @@ int ensure_lists(circkit_ctx* c, uint64_t entries, uint64_t segs)
 {
     if (entries > c->list_cap) {
         c->list_cap = 0;
-        for (int i = 0; i < N_TIERS; ++i) {
+        for (int i = 0; i < N_TIERS + 1; ++i) {
             if (c->d_lists[i]) { (void)hipFree(c->d_lists[i]); c->d_lists[i] = nullptr; }
             CK_HIP(c, hipMalloc(&c->d_lists[i], entries * sizeof(uint32_t)));
         }
@@ -355,7 +379,7 @@ int ensure_lists(circkit_ctx* c, uint64_t entries, uint64_t segs)
     if (segs > c->seg_alloc) {
         if (c->d_seg_counts) { (void)hipFree(c->d_seg_counts); c->d_seg_counts = nullptr; }
         c->seg_alloc = 0;
-        CK_HIP(c, hipMalloc(&c->d_seg_counts, N_TIERS * segs * sizeof(uint32_t)));
+        CK_HIP(c, hipMalloc(&c->d_seg_counts, (N_TIERS + 1) * segs * sizeof(uint32_t)));
         c->seg_alloc = segs;
     }
     return CIRCKIT_OK;
@@ -442,17 +466,27 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             else hipLaunchKernelGGL((canon_stream_kernel<StreamC2, false, false>), grid, block, 0, c->stream, a, mode);
         }
     }
-    unsigned nseg = G;              // segments / capacity of the list the next tier consumes
+    unsigned nseg = G;              // segments / capacity of the list the next stage consumes
     uint32_t seg_cap = cap;
+    {
+        // rescue pass over the streaming kernel's leftovers: segment for segment into the next list
+        const unsigned grid = nseg < (unsigned)N_CU * CK_RESCUE_BPC ? nseg : (unsigned)N_CU * CK_RESCUE_BPC;
+        a.list = c->d_lists[0]; a.list_count = c->d_seg_counts;
+        a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = 1;
+        a.defer_list = c->d_lists[1]; a.defer_count = c->d_seg_counts + c->seg_alloc; a.out_seg_cap = seg_cap;
+        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a);
+        else if (d_hash) hipLaunchKernelGGL((canon_rescue_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL((canon_rescue_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a);
+    }
     for (int t = 0; t < N_TIERS; ++t) {
         const bool last = t == N_TIERS - 1;
         const unsigned spb = t <= CK_TIER_KEEP ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
         const unsigned grid = (nseg + spb - 1) / spb;
-        a.list = c->d_lists[t]; a.list_count = c->d_seg_counts + (uint64_t)t * c->seg_alloc;
+        a.list = c->d_lists[t + 1]; a.list_count = c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb;
         // the last tier's leftovers go into the first list (long consumed by now): finish_giants() picks them up
-        a.defer_list = last ? c->d_lists[0] : c->d_lists[t + 1];
-        a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
+        a.defer_list = last ? c->d_lists[0] : c->d_lists[t + 2];
+        a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 2) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
         a.slice_dw = TIER_DW[t];
         if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a);

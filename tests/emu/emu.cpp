@@ -126,6 +126,14 @@ void wave_body(void* p)
     Launch* L = (Launch*)p;
     ck::canon_wave_loop(L->a, L->lds, L->lut, L->blk_count, L->block, L->nblocks, L->wib, 4);
 }
+void rescue_body(void* p)
+{
+    Launch* L = (Launch*)p;
+    const bool aux = L->a.out_index || L->a.out_strand || (L->a.flags & ck::CK_FLAG_FWD_ONLY);
+    if (aux) { ck::RescueState<true, true> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, true>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4); }
+    else if (L->a.out_hash) { ck::RescueState<true, false> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4); }
+    else { ck::RescueState<false, false> st; ck::canon_rescue_segment<false, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4); }
+}
 template <class C>
 void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
 {
@@ -162,7 +170,7 @@ void hash_body(void* q)
 extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                       uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
                                       uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
-                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast, uint32_t* n_fused_hash, int staged)
+                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast, uint32_t* n_fused_hash, int staged, uint32_t* n_rescued)
 {
     uint8_t comp[256];
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
@@ -194,7 +202,19 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
         cnt_f[b] = blk; total_f += blk;
     }
     if (n_fast) *n_fast = (uint32_t)n_records - total_f;
+    // rescue pass: the streaming kernel's leftovers that are eligible by themselves (same build choice as launch_canon)
+    std::vector<uint32_t> list_r((size_t)G * cap), cnt_r(G, 0);
+    uint32_t total_r = 0;
     L.a.list = list_f.data(); L.a.list_count = cnt_f.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1;
+    L.a.defer_list = list_r.data(); L.a.defer_count = cnt_r.data(); L.a.out_seg_cap = cap;
+    for (uint32_t b = 0; b < G; ++b) {
+        uint32_t blk = 0;
+        L.block = b; L.blk_count = &blk;
+        for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(rescue_body, &L); }
+        cnt_r[b] = blk; total_r += blk;
+    }
+    if (n_rescued) *n_rescued = total_f - total_r;
+    L.a.list = list_r.data(); L.a.list_count = cnt_r.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1;
     L.a.defer_list = list_a.data(); L.a.defer_count = cnt_a.data(); L.a.out_seg_cap = cap; L.a.slice_dw = slice_dw;
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;

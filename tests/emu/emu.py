@@ -20,6 +20,7 @@ def build():
 
 _lib = None
 last_fast_count = 0
+last_rescued_count = 0
 last_fused_hash_count = 0
 
 
@@ -35,7 +36,7 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.emu_canonicalize_batch.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4 + \
-            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
@@ -54,13 +55,15 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     ndef = ctypes.c_uint32(0)
     nfast = ctypes.c_uint32(0)
     nfused = ctypes.c_uint32(0)
+    nresc = ctypes.c_uint32(0)
     # want_aux=False: no rotation index / strand outputs -- the streaming kernel's leaner builds (see launch_canon)
     st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data,
                                      idx.ctypes.data if want_aux else None, strand.ctypes.data if want_aux else None,
                                      hs.ctypes.data if want_hash else None,
-                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged))
+                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged), ctypes.byref(nresc))
     assert st >= 0, "emulator rejected the launch (unknown `staged` geometry?)"
-    global last_fast_count, last_fused_hash_count
+    global last_fast_count, last_fused_hash_count, last_rescued_count
+    last_rescued_count = nresc.value
     last_fast_count = nfast.value
     last_fused_hash_count = nfused.value
     assert (out[lead + len(data):] == 0x3F).all() and (raw_out[:skew + lead] == 0x3F).all(), "kernel wrote outside the batch"

@@ -172,3 +172,29 @@ def test_two_words_per_lane_records_take_the_streaming_kernel():
     seqs = seqsets.random_mixed(973, 20, 2033, 2100) + seqsets.random_mixed(974, 12, 1009, 2032, b"ACGTN")
     check(seqs, staged=emu.TWO_ROW[0], slice_dw=4096)
     assert emu.last_fast_count == 0
+
+
+def test_rescue_pass_takes_short_records_of_unstaged_groups():
+    """One long record per group of 16 pushes every group's span past its LDS image; the short pure-ACGT records around
+    it must still be handled by the register routine (rescue pass), not by the LDS tiers -- and stay correct."""
+    rng = np.random.default_rng(980)
+    seqs = []
+    for g in range(6):
+        block = seqsets.random_mixed(981 + g, 15, 100, 1008)
+        block.insert(int(rng.integers(0, 16)), seqsets.random_mixed(990 + g, 1, 30000, 30000)[0])
+        seqs += block
+    seqs += seqsets.random_mixed(999, 5, 100, 900, b"ACGTN")            # not eligible: must reach the tiers
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    for want_hash, want_aux in ((False, False), (True, False), (True, True)):
+        out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=want_hash, want_aux=want_aux, staged=1,
+                                                                   slice_dw=8192, n_waves=24)
+        assert emu.last_fast_count == 0                                  # no group could be staged
+        assert emu.last_rescued_count == 6 * 15
+        for i, s in enumerate(seqs):
+            a, b = int(offs[i]), int(offs[i + 1])
+            assert out[a:b].tobytes() == want[i][0], (i, len(s))
+            if want_hash:
+                assert int(h[i]) == O.xxh3_64(want[i][0])
+            if want_aux:
+                assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2])
