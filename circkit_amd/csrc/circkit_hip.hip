@@ -155,10 +155,11 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
 {
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
+    const ck::XWaveConst xk = ck::xwave_const();
     if (!hashed) {
         for (uint64_t r = wave; r < n_records; r += n_waves) {
             const uint64_t off = offsets[r];
-            const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
+            const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off), xk);
             if (ck::lane_id() == 0) out[r] = h;
         }
         return;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
             const uint64_t r = base + (uint64_t)ck::ffs64(todo);
             todo &= todo - 1;
             const uint64_t off = offsets[r];
-            const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off));
+            const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off), xk);
             if (ck::lane_id() == 0) out[r] = h;
         }
     }

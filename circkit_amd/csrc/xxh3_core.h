@@ -132,33 +132,73 @@ CK_DEV uint64_t xsum_stripes(uint64_t v)   // sum over the 16 lanes that share (
     return v;
 }
 
-CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len)
+// Per-lane constants of the long-input path (lane = stripe s = lane >> 2, accumulator pair j = lane & 3): secret
+// words and initial accumulators.  A kernel that hashes many records computes them once per wave.
+struct XWaveConst {
+    uint64_t k0, k1;      // stripe cell:   secret at 8 s + 16 j, + 8
+    uint64_t sc0, sc1;    // scramble:      secret at 128 + 16 j, + 8
+    uint64_t l0, l1;      // last stripe:   secret at 121 + 16 j, + 8
+    uint64_t m0, m1;      // final merge:   secret at 11 + 16 j, + 8
+    uint64_t i0, i1;      // initial accumulators {P32_3, P64_1, P64_2, P64_3, P64_4, P32_2, P64_5, P32_1}[2j, 2j+1]
+};
+CK_DEV XWaveConst xwave_const()
+{
+    const uint32_t lane = lane_id(), j = lane & 3, s = lane >> 2;
+    XWaveConst k;
+    k.k0 = xsec64(8 * s + 16 * j); k.k1 = xsec64(8 * s + 16 * j + 8);
+    k.sc0 = xsec64(128 + 16 * j); k.sc1 = xsec64(128 + 16 * j + 8);
+    k.l0 = xsec64(121 + 16 * j); k.l1 = xsec64(121 + 16 * j + 8);
+    k.m0 = xsec64(11 + 16 * j); k.m1 = xsec64(11 + 16 * j + 8);
+    k.i0 = j == 0 ? XP32_3 : j == 1 ? XP64_2 : j == 2 ? XP64_4 : XP64_5;
+    k.i1 = j == 0 ? XP64_1 : j == 1 ? XP64_3 : j == 2 ? XP32_2 : XP32_1;
+    return k;
+}
+CK_DEV void xcell_k(uint64_t d0, uint64_t d1, uint64_t s0, uint64_t s1, uint64_t& a0, uint64_t& a1)
+{
+    const uint64_t k0 = d0 ^ s0, k1 = d1 ^ s1;
+    a0 += d1 + (uint64_t)(uint32_t)k0 * (k0 >> 32);
+    a1 += d0 + (uint64_t)(uint32_t)k1 * (k1 >> 32);
+}
+
+// XXH3-64 (seed 0) of in[0, len) computed by one wave; every lane returns the hash.  Long inputs: lane = (stripe,
+// accumulator pair) cell of a 1024-byte block; the loads of up to four blocks and of the last stripe are all issued
+// before the first is consumed (a 1-2 kb record is otherwise three dependent round trips).
+CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len, const XWaveConst& k)
 {
     if (len <= 240) return xxh3_short(in, len);
     const uint32_t lane = lane_id(), j = lane & 3, s = lane >> 2;
-    // accumulator init: {P32_3, P64_1, P64_2, P64_3, P64_4, P32_2, P64_5, P32_1}
-    uint64_t a0 = j == 0 ? XP32_3 : j == 1 ? XP64_2 : j == 2 ? XP64_4 : XP64_5;
-    uint64_t a1 = j == 0 ? XP64_1 : j == 1 ? XP64_3 : j == 2 ? XP32_2 : XP32_1;
-    const uint32_t nb = (len - 1) / 1024;
-    for (uint32_t b = 0; b <= nb; ++b) {
-        const uint32_t stripes = b < nb ? 16u : ((len - 1) - 1024 * nb) / 64;
-        uint64_t c0 = 0, c1 = 0;
-        if (s < stripes) {
-            const uint8_t* p = in + 1024 * b + 16 * lane;
-            xcell(xrd64(p), xrd64(p + 8), 8 * s + 16 * j, c0, c1);
+    uint64_t a0 = k.i0, a1 = k.i1;
+    const uint32_t nb = (len - 1) / 1024;                  // full blocks before the last (partial or full) one
+    const uint8_t* lp = in + len - 64 + 16 * j;
+    const uint64_t ld0 = xrd64(lp), ld1 = xrd64(lp + 8);   // last stripe, in flight with the blocks below
+    constexpr uint32_t U = 4;
+    for (uint32_t b0 = 0; b0 <= nb; b0 += U) {
+        uint64_t d0[U], d1[U];
+        bool on[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t b = b0 + u;
+            const uint32_t stripes = b < nb ? 16u : ((len - 1) - 1024 * nb) / 64;
+            on[u] = b <= nb && s < stripes;
+            d0[u] = d1[u] = 0;
+            if (on[u]) { const uint8_t* p = in + 1024 * b + 16 * lane; d0[u] = xrd64(p); d1[u] = xrd64(p + 8); }
         }
-        a0 += xsum_stripes(c0);
-        a1 += xsum_stripes(c1);
-        if (b < nb) {   // scramble with the last 64 secret bytes
-            a0 = (a0 ^ (a0 >> 47) ^ xsec64(128 + 16 * j)) * XP32_1;
-            a1 = (a1 ^ (a1 >> 47) ^ xsec64(128 + 16 * j + 8)) * XP32_1;
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t b = b0 + u;
+            if (b > nb) break;
+            uint64_t c0 = 0, c1 = 0;
+            if (on[u]) xcell_k(d0[u], d1[u], k.k0, k.k1, c0, c1);
+            a0 += xsum_stripes(c0);
+            a1 += xsum_stripes(c1);
+            if (b < nb) {   // scramble with the last 64 secret bytes
+                a0 = (a0 ^ (a0 >> 47) ^ k.sc0) * XP32_1;
+                a1 = (a1 ^ (a1 >> 47) ^ k.sc1) * XP32_1;
+            }
         }
     }
-    {   // last stripe: the final 64 bytes, secret offset 192 - 64 - 7
-        const uint8_t* p = in + len - 64 + 16 * j;
-        xcell(xrd64(p), xrd64(p + 8), 121 + 16 * j, a0, a1);
-    }
-    uint64_t t = xfold(a0 ^ xsec64(11 + 16 * j), a1 ^ xsec64(11 + 16 * j + 8));
+    xcell_k(ld0, ld1, k.l0, k.l1, a0, a1);                 // last stripe: the final 64 bytes, secret offset 192 - 64 - 7
+    uint64_t t = xfold(a0 ^ k.m0, a1 ^ k.m1);
 #pragma unroll
     for (uint32_t m = 1; m <= 2; m <<= 1) {
         const uint32_t lo = shfl((uint32_t)t, lane ^ m), hi = shfl((uint32_t)(t >> 32), lane ^ m);
@@ -166,5 +206,6 @@ CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len)
     }
     return xaval3((uint64_t)len * XP64_1 + t);
 }
+CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len) { return xxh3_64_wave(in, len, xwave_const()); }
 
 }  // namespace ck
