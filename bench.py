@@ -206,7 +206,8 @@ def main():
             O.canonicalize_batch(h_in[:S1 * L], h_off[:S1 + 1], True, False, threads=1)
             one_core = S1 / (time.perf_counter() - c1)
             result["cpu_baseline"] = {
-                "value": S / cdt, "unit": "sequences/s", "cores": cores, "kind": "port", "one_core_value": one_core,
+                "value": S / cdt, "unit": "sequences/s", "cores": cores, "host_cores_visible": len(os.sched_getaffinity(0)),
+                "kind": "port", "one_core_value": one_core,
                 "sample": "first %d records of the same device-generated batch; C restatement of the reference "
                           "path (linear-time byte-indexed Duval variant, faster than the reference's O(n^2) "
                           "chars().nth() loop), %d pthreads" % (S, cores),
