@@ -166,13 +166,19 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
     }
     for (uint64_t base = (uint64_t)wave * 64; base < n_records; base += (uint64_t)n_waves * 64) {
         const uint64_t mine = base + ck::lane_id();
-        uint64_t todo = ck::ballot(mine < n_records && !hashed[mine]);
+        const bool need = mine < n_records && !hashed[mine];
+        uint64_t todo = ck::ballot(need);
+        if (!todo) continue;
+        // the chunk's offsets in one coalesced load (lane L: record base + L), handed out by v_readlane: no dependent
+        // round trip in front of every record
+        const uint64_t my_off = need ? offsets[mine] : 0;
+        const uint32_t my_len = need ? (uint32_t)(offsets[mine + 1] - my_off) : 0u;
         while (todo) {
-            const uint64_t r = base + (uint64_t)ck::ffs64(todo);
+            const uint32_t l = (uint32_t)ck::ffs64(todo);
             todo &= todo - 1;
-            const uint64_t off = offsets[r];
-            const uint64_t h = ck::xxh3_64_wave(bytes + off, (uint32_t)(offsets[r + 1] - off), xk);
-            if (ck::lane_id() == 0) out[r] = h;
+            const uint64_t off = ((uint64_t)ck::readlane((uint32_t)(my_off >> 32), l) << 32) | ck::readlane((uint32_t)my_off, l);
+            const uint64_t h = ck::xxh3_64_wave(bytes + off, ck::readlane(my_len, l), xk);
+            if (ck::lane_id() == 0) out[base + l] = h;
         }
     }
 }
