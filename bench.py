@@ -38,8 +38,8 @@ def pmc_traffic(n_records, length):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU")
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--cpu-sample", type=int, default=3_000_000,
