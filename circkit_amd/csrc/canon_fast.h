@@ -207,8 +207,8 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
 // ------------------------------------------------------------------------------------------------------------
 // Two words per lane: records of 1009..2032 bases (the 1.0-1.7 kb circular RNAs -- obelisks, deltaviruses -- sit
 // here).  Lane t holds words 2t and 2t+1 (symbols [32t, 32t+32)); word q of a strand therefore lives in lane q>>1,
-// register q&1, and every cross-lane access goes through word2().  Same algorithm and exits as fast_canon; the
-// XXH3 of these records is left to the xxh3 pass (their long-input loop needs the scramble step).
+// register q&1, and every cross-lane access goes through word2().  Same algorithm and exits as fast_canon; XXH3 by
+// fast_hash2 (two blocks with the scramble step between them).
 constexpr uint32_t FAST2_MAX_N = 2032;
 CK_DEV bool fast2_eligible(uint32_t n) { return n - (FAST_MAX_N + 1) <= FAST2_MAX_N - (FAST_MAX_N + 1); }
 
@@ -251,11 +251,50 @@ CK_DEV uint32_t fast2x_locate(uint32_t E0, uint32_t E1, uint32_t E0n, uint64_t h
     return pos;
 }
 
+// XXH3-64 of a two-words-per-lane record (1009..2032 bytes: one or two 1024-byte blocks), fused like fast_hash: per
+// block the lanes re-fetch the canonical bytes in the hash's own layout (lane t = cell (stripe t>>2, pair t&3) of the
+// block), accumulate, sum over the stripes, and the first block is followed by XXH3's scramble; last stripe, merge and
+// avalanche as in fast_hash.
+CK_DEV uint64_t fast_hash2(const FastHashConst& hc, const uint32_t* lut, uint32_t E0, uint32_t E1, uint32_t idx, uint32_t n)
+{
+    const uint32_t t = lane_id(), j = t & 3;
+    const uint32_t nb = (n - 1) >> 10;                                   // 0 or 1 full blocks before the last one
+    uint64_t a0 = hc.i0, a1 = hc.i1;                                     // meaningful in lanes with (t & 15) >= 12
+    for (uint32_t b = 0; b <= nb; ++b) {
+        const uint32_t stripes = b < nb ? 16u : ((n - 1) - 1024 * nb) / 64;
+        const u32x4 cell = fast_decode(lut, reg_sym_word2(E0, E1, idx + 1024 * b + 16 * t, n));
+        const uint64_t d0 = ((uint64_t)cell.y << 32) | cell.x, d1 = ((uint64_t)cell.w << 32) | cell.z;
+        const uint64_t x0 = d0 ^ hc.k0, x1 = d1 ^ hc.k1;
+        const bool on = t < 4 * stripes;
+        uint64_t c0 = on ? d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32) : 0;
+        uint64_t c1 = on ? d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32) : 0;
+        dpp_rowsum4_u64x2(c0, c1);
+        c0 = shfl_xor_add64(c0, 16); c1 = shfl_xor_add64(c1, 16);
+        c0 = shfl_xor_add64(c0, 32); c1 = shfl_xor_add64(c1, 32);
+        a0 += c0; a1 += c1;
+        if (b < nb) {                                                    // scramble with the last 64 secret bytes
+            a0 = (a0 ^ (a0 >> 47) ^ xsec64(128 + 16 * j)) * XP32_1;
+            a1 = (a1 ^ (a1 >> 47) ^ xsec64(128 + 16 * j + 8)) * XP32_1;
+        }
+    }
+    {   // last stripe: the final 64 bytes, pair j = bytes [n-64+16j, n-48+16j)
+        const u32x4 bb = fast_decode(lut, reg_sym_word2(E0, E1, idx + (n - 64) + 16 * j, n));
+        const uint64_t d0 = ((uint64_t)bb.y << 32) | bb.x, d1 = ((uint64_t)bb.w << 32) | bb.z;
+        const uint64_t x0 = d0 ^ hc.l0, x1 = d1 ^ hc.l1;
+        a0 += d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32);
+        a1 += d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32);
+    }
+    uint64_t r = xfold(a0 ^ hc.m0, a1 ^ hc.m1);
+    r = dpp_quadsum_u64(r);
+    const uint64_t h = xaval3((uint64_t)n * XP64_1 + r);
+    return ((uint64_t)readlane((uint32_t)(h >> 32), 15) << 32) | readlane((uint32_t)h, 15);
+}
+
 // W0 / W1: lane t = symbols [32t, 32t+16) / [32t+16, 32t+32) of the record (garbage past n); bad = any lane of the
 // record's chunks holds a byte outside ACGT.
-template <bool AUX>
-CK_DEV bool fast_canon2(const CanonArgs& a, const uint32_t* lut, uint32_t rec, uint64_t off, uint32_t n, uint32_t W0, uint32_t W1,
-                        bool bad)
+template <bool HASH, bool AUX>
+CK_DEV bool fast_canon2(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
+                        uint32_t W0, uint32_t W1, bool bad)
 {
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
@@ -301,7 +340,8 @@ CK_DEV bool fast_canon2(const CanonArgs& a, const uint32_t* lut, uint32_t rec, u
     uint32_t iF = idx;
     if (AUX && a.out_index && !fwd) iF = fast2x_locate(W0, W1, W0n, ballot(mF0 == MF), ballot(mF1 == MF), MF, n, shv, uF);
     if (bad || tie || !uE || !uF) return false;
-    if (a.out_bytes) {
+    const bool hash = HASH && a.out_hash != nullptr;
+    if (a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL))) {
 #pragma unroll
         for (uint32_t k = 0; k < 2; ++k) {
             // every stored window is a full 16 bytes: the record's last window is pulled back to end exactly at n
@@ -309,6 +349,10 @@ CK_DEV bool fast_canon2(const CanonArgs& a, const uint32_t* lut, uint32_t rec, u
             const u32x4 cell = fast_decode(lut, reg_sym_word2(E0, E1, idx + o, n));
             if (ob < n) store16(a.out_bytes + off + o, cell);
         }
+    }
+    if (hash) {
+        const uint64_t h = fast_hash2(hc, lut, E0, E1, idx, n);
+        if (t == 0) { a.out_hash[rec] = h; a.hashed[rec] = 1; }
     }
     if (AUX && t == 0) {
         if (a.out_index) a.out_index[rec] = fwd ? idx : (idx + iF >= n ? idx + iF - n : idx + iF);

@@ -139,7 +139,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 const uint64_t bad0 = ballot(m0 != 0) & (~0ull >> (64 - ((nch + 1) >> 1)));       // chunk 2t   < nch
                 const uint64_t bad1 = ballot(m1 != 0) & ((nch >> 1) >= 64 ? ~0ull : (1ull << (nch >> 1)) - 1);   // chunk 2t+1 < nch
                 const uint32_t sh2 = 32 - 2 * a16;
-                done = fast_canon2<AUX>(a, lut, rec, off, n, lshr64(P0, P1, sh2), lshr64(P1, wave_shl1(P0), sh2), (bad0 | bad1) != 0);
+                done = fast_canon2<HASH, AUX>(a, lut, hc, rec, off, n, lshr64(P0, P1, sh2), lshr64(P1, wave_shl1(P0), sh2), (bad0 | bad1) != 0);
             } else if (q[0].ok && fast_eligible(n)) {
                 // lane t packs the aligned chunk c0 + t of the image; the record starts a16 bytes into chunk c0, so
                 // the byte funnel is done on the packed words: 2*a16 bits, with the next lane's word behind

@@ -167,6 +167,10 @@ def test_two_words_per_lane_records_take_the_streaming_kernel():
         check(seqs, staged=k)
         wpb, rpw, _ = emu.STAGED_GEOMETRIES[k]
         assert emu.last_fast_count == len(seqs) - ((len(seqs) - 1) % (wpb * rpw) + 1)      # all but the batch's last group
+    data, offs = seqsets.pack(seqs)
+    _, _, _, h, _, _ = emu.canonicalize_batch(data, offs, want_hash=True, want_aux=False, staged=emu.TWO_ROW[0])
+    assert emu.last_fused_hash_count == emu.last_fast_count > 0                            # XXH3 fused (two blocks + scramble)
+    assert [int(x) for x in h] == [O.xxh3_64(O.canonicalize(s)) for s in seqs]
     check(seqs, staged=1, slice_dw=4096)
     assert emu.last_fast_count == 0                                                        # the one-word build leaves them
     seqs = seqsets.random_mixed(973, 20, 2033, 2100) + seqsets.random_mixed(974, 12, 1009, 2032, b"ACGTN")
