@@ -181,16 +181,20 @@ struct RescueState {        // per-wave constants of the rescue pass (kept acros
     FastHashConst hc{};
     FastShape shape;
 };
-// one wave's share of list segment `seg_index`; failures are appended to the SAME segment index of the output list
+// one wave's share of list segment `seg_index`; failures are appended to the SAME segment index of the output list.
+// all_records: the streaming kernel did not run (a batch with so many long records that hardly any group could be
+// staged): segment s then stands for records [s * in_seg_cap, (s + 1) * in_seg_cap).
 template <bool HASH, bool AUX>
 CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, RescueState<HASH, AUX>& st, uint32_t* seg_count, uint32_t seg_index,
-                                 uint32_t wib, uint32_t wpb)
+                                 uint32_t wib, uint32_t wpb, bool all_records)
 {
     const uint32_t t = lane_id();
-    const uint32_t count = a.list_count[seg_index];
-    const uint32_t* seg = a.list + (uint64_t)seg_index * a.in_seg_cap;
+    const uint64_t first = (uint64_t)seg_index * a.in_seg_cap;
+    const uint32_t count = all_records ? (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.in_seg_cap ? a.n_records - first : a.in_seg_cap))
+                                       : a.list_count[seg_index];
+    const uint32_t* seg = a.list + first;
     for (uint32_t i = wib; i < count; i += wpb) {
-        const uint32_t rec = seg[i];
+        const uint32_t rec = all_records ? (uint32_t)first + i : seg[i];
         const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
         bool done = false;
         if (len <= FAST_MAX_N && fast_eligible((uint32_t)len)) {

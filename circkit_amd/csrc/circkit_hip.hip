@@ -98,21 +98,30 @@ using StreamCAux2 = ck::StreamCfg<4, 2, 2, 2>;
 // count[0] must be 0 on entry.
 __global__ __launch_bounds__(256) void stream_count_kernel(const uint64_t* offsets, uint64_t n, uint32_t* count)
 {
-    uint32_t mine = 0;
+    uint32_t two = 0, lng = 0;          // records of 1009..2032 bases / longer ones (no build can stage their group)
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const uint64_t len = offsets[i + 1] - offsets[i];
-        mine += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
+        two += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
+        lng += len > ck::FAST2_MAX_N;
     }
-    const uint64_t total = ck::wave_sum_u64(mine);
-    if (ck::lane_id() == 0 && total) atomicAdd(count, (uint32_t)total);
+    const uint64_t t2 = ck::wave_sum_u64(two), tl = ck::wave_sum_u64(lng);
+    if (ck::lane_id() == 0 && t2) atomicAdd(count, (uint32_t)t2);
+    if (ck::lane_id() == 0 && tl) atomicAdd(count + 1, (uint32_t)tl);
+}
+// 1 / 2: which build of the streaming kernel; 3: neither -- with one record in eight longer than 2032 bases at most
+// 12 % of the 16-record groups could be staged, and the rescue pass takes every record straight away
+__host__ __device__ inline uint32_t stream_mode(uint64_t two, uint64_t lng, uint64_t n)
+{
+    return lng && lng * 8 >= n ? 3u : (two && two * 4 >= n ? 2u : 1u);
 }
 // Rescue pass (canon_stream.h): the streaming kernel's leftovers that are eligible by themselves, one wave per record.
 // A small persistent grid walks the list segments (a batch the streaming kernel handled completely leaves them
 // empty: the pass then costs a microsecond, not the dispatch of one workgroup per segment); segment s of the input
 // list yields segment s of the output list, so the tiers behind keep their geometry.
 template <bool HASH, bool AUX>
-__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a)
+__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, const uint32_t* mode, uint32_t host_mode)
 {
+    const bool all_records = (host_mode ? host_mode : *mode) == 3;       // the streaming kernel stood this batch out
     __shared__ uint32_t lut[256], seg_count;
     ck::fast_lut_init(lut, threadIdx.x, 256);
     ck::RescueState<HASH, AUX> st;
@@ -121,7 +130,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a)
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
         if (threadIdx.x == 0) seg_count = 0;
         __syncthreads();
-        ck::canon_rescue_segment<HASH, AUX>(a, lut, st, &seg_count, sgm, wib, 4);
+        ck::canon_rescue_segment<HASH, AUX>(a, lut, st, &seg_count, sgm, wib, 4, all_records);
         __syncthreads();
         if (threadIdx.x == 0) a.defer_count[sgm] = seg_count;
     }
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a)
 
 __global__ void stream_mode_kernel(const uint32_t* count, uint64_t n, uint32_t* mode)
 {
-    *mode = (uint64_t)count[0] * 4 >= n && count[0] ? 2u : 1u;
+    *mode = stream_mode(count[0], count[1], n);
 }
 
 template <class StreamC, bool HASH, bool AUX>
@@ -439,6 +448,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
+    uint32_t stream_rows = 0;       // 1 / 2 / 3 when the host knows the batch's mode (see stream_mode), 0 = the device word decides
     {
         // three builds of the streaming kernel: canonical bytes only (the headline), + fused XXH3 (uniq), and the
         // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr)
@@ -455,19 +465,20 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const uint32_t* mode = nullptr;
         if (!rows) {
             mode = c->d_counters + 5;
-            CK_HIP(c, hipMemsetAsync(c->d_counters + 6, 0, 4, c->stream));
+            CK_HIP(c, hipMemsetAsync(c->d_counters + 6, 0, 8, c->stream));
             hipLaunchKernelGGL(stream_count_kernel, dim3(N_CU), dim3(256), 0, c->stream, d_offsets, n, c->d_counters + 6);
             hipLaunchKernelGGL(stream_mode_kernel, dim3(1), dim3(1), 0, c->stream, (const uint32_t*)(c->d_counters + 6), n, c->d_counters + 5);
             CK_HIP(c, hipMemcpyAsync(c->h_mode, c->d_counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
             CK_HIP(c, hipEventRecord(c->mode_ev, c->stream));
             c->mode_key = d_offsets; c->mode_key_n = n; c->mode_pending = true; c->mode_known = 0;
         }
-        if (rows != 2) {
+        stream_rows = rows;
+        if (rows != 2 && rows != 3) {
             if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux, true, true>), grid, block_aux, 0, c->stream, a, mode);
             else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC, true, false>), grid, block, 0, c->stream, a, mode);
             else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false>), grid, block, 0, c->stream, a, mode);
         }
-        if (rows != 1) {
+        if (rows != 1 && rows != 3) {
             if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux2, true, true>), grid, block_aux, 0, c->stream, a, mode);
             else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC2, true, false>), grid, block, 0, c->stream, a, mode);
             else hipLaunchKernelGGL((canon_stream_kernel<StreamC2, false, false>), grid, block, 0, c->stream, a, mode);
@@ -481,9 +492,10 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.list = c->d_lists[0]; a.list_count = c->d_seg_counts;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = 1;
         a.defer_list = c->d_lists[1]; a.defer_count = c->d_seg_counts + c->seg_alloc; a.out_seg_cap = seg_cap;
-        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a);
-        else if (d_hash) hipLaunchKernelGGL((canon_rescue_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL((canon_rescue_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a);
+        const uint32_t* mode = c->d_counters + 5;
+        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a, mode, stream_rows);
+        else if (d_hash) hipLaunchKernelGGL((canon_rescue_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a, mode, stream_rows);
+        else hipLaunchKernelGGL((canon_rescue_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a, mode, stream_rows);
     }
     for (int t = 0; t < N_TIERS; ++t) {
         const bool last = t == N_TIERS - 1;
@@ -625,10 +637,14 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     if (total) CK_HIP(c, hipMemcpyAsync(c->d_in, bytes, total, hipMemcpyHostToDevice, c->stream));
     CK_HIP(c, hipMemcpyAsync(c->d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     const bool need_bytes = out || hash;
-    uint64_t two_word = 0;                            // the host has the offsets: it picks the streaming kernel's build
-    for (uint64_t i = 0; i < n; ++i) { const uint64_t len = offsets[i + 1] - offsets[i]; two_word += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N; }
+    uint64_t two_word = 0, longer = 0;                // the host has the offsets: it picks the streaming kernel's build
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t len = offsets[i + 1] - offsets[i];
+        two_word += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
+        longer += len > ck::FAST2_MAX_N;
+    }
     rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
-                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags, two_word * 4 >= n && two_word ? 2u : 1u);
+                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags, stream_mode(two_word, longer, n));
     if (rc) return rc;
     if ((rc = finish_giants(c))) return rc;
     if (out && total) CK_HIP(c, hipMemcpyAsync(out, c->d_out, total, hipMemcpyDeviceToHost, c->stream));

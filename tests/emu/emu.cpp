@@ -120,7 +120,7 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t* blk_count; uint32_t block, nblocks, wib; };
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false; };
 void wave_body(void* p)
 {
     Launch* L = (Launch*)p;
@@ -130,9 +130,9 @@ void rescue_body(void* p)
 {
     Launch* L = (Launch*)p;
     const bool aux = L->a.out_index || L->a.out_strand || (L->a.flags & ck::CK_FLAG_FWD_ONLY);
-    if (aux) { ck::RescueState<true, true> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, true>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4); }
-    else if (L->a.out_hash) { ck::RescueState<true, false> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4); }
-    else { ck::RescueState<false, false> st; ck::canon_rescue_segment<false, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4); }
+    if (aux) { ck::RescueState<true, true> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, true>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
+    else if (L->a.out_hash) { ck::RescueState<true, false> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
+    else { ck::RescueState<false, false> st; ck::canon_rescue_segment<false, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
 }
 template <class C>
 void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
@@ -177,8 +177,11 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     const char *x = "AGCTYRWSKMDVHBN", *y = "TCGARYWSMKHBDVN";
     for (int i = 0; x[i]; ++i) { comp[(uint8_t)x[i]] = y[i]; comp[(uint8_t)x[i] + 32] = y[i] + 32; }
     const uint32_t G = (n_waves + 3) / 4;
-    if (staged < 1 || staged > (int)(sizeof(kStream) / sizeof(kStream[0]))) return -1;
-    const StreamVariant* sv = &kStream[staged - 1];
+    // staged == 0: the batch's mode is 3 (launch_canon: too many long records to stage anything) -- no streaming
+    // kernel, the rescue pass takes every record
+    if (staged < 0 || staged > (int)(sizeof(kStream) / sizeof(kStream[0]))) return -1;
+    const StreamVariant* sv = &kStream[staged ? staged - 1 : 0];
+    const bool all_records = staged == 0;
     const uint64_t per_step = sv->group, steps = (n_records + per_step - 1) / per_step;
     const uint32_t cap = (uint32_t)(per_step * ((steps + G - 1) / G)) + 4;
     std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
@@ -195,12 +198,14 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a.defer_list = list_f.data(); L.a.defer_count = cnt_f.data(); L.a.out_seg_cap = cap;
     L.lds = lds.data(); L.lut = lut; L.nblocks = G;
     uint32_t total_f = 0, total_a = 0;
-    for (uint32_t b = 0; b < G; ++b) {
+    for (uint32_t b = 0; b < G && !all_records; ++b) {
         uint32_t blk = 0;
         L.block = b; L.blk_count = &blk;
         ck::emu::run_block(sv->body, &L, sv->wpb);
         cnt_f[b] = blk; total_f += blk;
     }
+    if (all_records) total_f = (uint32_t)n_records;
+    L.all_records = all_records;
     if (n_fast) *n_fast = (uint32_t)n_records - total_f;
     // rescue pass: the streaming kernel's leftovers that are eligible by themselves (same build choice as launch_canon)
     std::vector<uint32_t> list_r((size_t)G * cap), cnt_r(G, 0);

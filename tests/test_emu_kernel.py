@@ -202,3 +202,25 @@ def test_rescue_pass_takes_short_records_of_unstaged_groups():
                 assert int(h[i]) == O.xxh3_64(want[i][0])
             if want_aux:
                 assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2])
+
+
+def test_mode_3_rescue_pass_takes_every_record():
+    """Batches in which one record in eight is longer than 2032 bases skip the staged kernel (launch_canon, mode 3): the
+    rescue pass walks all records (virtual list segments) and hands what it cannot take to the tiers."""
+    seqs = seqsets.random_mixed(1001, 70, 48, 1008) + seqsets.random_mixed(1002, 20, 3000, 9000) + \
+        seqsets.random_mixed(1003, 10, 1, 47) + seqsets.random_mixed(1004, 10, 100, 900, b"ACGTN") + [b"", b"ACGT" * 100]
+    rng = np.random.default_rng(1005)
+    seqs = [seqs[i] for i in rng.permutation(len(seqs))]
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    for want_hash, want_aux in ((False, False), (True, False), (True, True)):
+        out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=want_hash, want_aux=want_aux, staged=0,
+                                                                   slice_dw=4096, n_waves=12)
+        assert emu.last_rescued_count >= 65                          # the eligible short ones (minus rare ties)
+        for i, s in enumerate(seqs):
+            a, b = int(offs[i]), int(offs[i + 1])
+            assert out[a:b].tobytes() == want[i][0], (i, len(s))
+            if want_hash:
+                assert int(h[i]) == O.xxh3_64(want[i][0])
+            if want_aux and len(s):
+                assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2])

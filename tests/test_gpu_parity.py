@@ -516,3 +516,32 @@ def test_randomized_rare_paths_long_profile():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+def test_device_api_batch_full_of_long_records(ctx, O):
+    """Mode 3 of launch_canon decided on the device: with one record in eight beyond 2032 bases the staged kernel is
+    skipped and the rescue pass walks every record (first call: decided by the counting kernel; later: remembered)."""
+    import torch
+    from tests import seqsets
+    seqs = seqsets.random_mixed(111, 400, 48, 1008) + seqsets.random_mixed(112, 150, 2500, 9000) + \
+        seqsets.random_mixed(113, 60, 1009, 2032) + seqsets.random_mixed(114, 40, 1, 47) + seqsets.random_mixed(115, 40, 100, 900, b"ACGTN")
+    rng = np.random.default_rng(116)
+    seqs = [seqs[i] for i in rng.permutation(len(seqs))]
+    data, offs = seqsets.pack(seqs)
+    n = len(seqs)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    for rep in range(3):
+        d_out = torch.zeros_like(d_bytes)
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep else None,
+                                      out_index=d_idx if rep == 2 else None)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), exp), rep
+        if rep:
+            assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    ctx.use_own_stream()
