@@ -3,9 +3,11 @@
 
 A "step" is one pass of the hot path (circkit_canonicalize_batch_device: both strands' least rotation,
 select, emit canonical bytes) over one device-resident CSR batch.  Default workload = BASELINE.json
-configs[1]: 10,000,000 records x 1,000 b, i.i.d. uniform ACGT, seed 42, generated ON the device.
-Records shard across GPUs with no data-path collective (weak scaling: every rank owns --records
-records); the only collectives are the timing barrier and a MAX over ranks.
+configs[1]: 10,000,000 records x 1,000 b, i.i.d. uniform ACGT, seed 42, generated ON the device; with
+--gpus 8 it is configs[4]: 100M records, 12.5M per GPU.  Records shard across GPUs by contiguous global
+index ranges with no data-path collective (weak scaling); the only collectives of `canonicalize` are the
+timing barrier and a MAX over ranks.  `--workload uniq` adds the one real exchange of the path: the
+hash-range all-to-all of circkit_amd/uniq.py over RCCL, inside the timed step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -22,17 +24,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
-def pmc_traffic(n_records, length):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes
-    (profiles/traffic.json; bench.py cannot collect PMC counters itself).  None if the profile is for
-    another workload."""
+def pmc_traffic(workload):
+    """(HBM bytes per step, source) from the committed rocprofv3 --pmc passes: bench.py cannot collect PMC counters
+    itself, so the number is the one of profiles/traffic.json when that profile is of this very workload."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if t.get("workload") == "canonicalize %d x %d" % (n_records, length):
-            return t["traffic_bytes"]
+        for entry in t.get("entries", [t]):
+            if entry.get("workload") == workload:
+                return entry["traffic_bytes"], "profiles/traffic.json (%s)" % entry.get("source", "rocprofv3 --pmc, separate passes")
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -40,11 +42,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--records", type=int, default=10_000_000, help="records per GPU")
+    ap.add_argument("--records", type=int, default=None,
+                    help="records per GPU (default: 10M; 12.5M at --gpus 8 = BASELINE configs[4]; 1M for --workload mixed)")
     ap.add_argument("--length", type=int, default=1000)
-    ap.add_argument("--cpu-sample", type=int, default=3_000_000,
-                    help="records timed on the host cores (rank 0, N=1): ~20 core-seconds of work at the default")
+    ap.add_argument("--n-frac", type=float, default=0.0, help="fraction of bases replaced by N (SURVEY 8d: the 1 %% N variants)")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="records timed on the host cores (rank 0, N=1); default: ~20k records per core")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--exchange", default="partition", choices=["partition", "allgather"], help="uniq at --gpus > 1")
     ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
                     help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
                          "strand duplicates, hash + first-seen); mixed = configs[3] (1M records, L ~ 1/L on [200, 20000])")
@@ -64,70 +69,54 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("CIRCKIT_BENCH_FORCE_DIST") == "1"   # the latter: rehearse the RCCL path on one GPU
+    force_dist = os.environ.get("CIRCKIT_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path on one GPU
+    use_dist = world > 1 or force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import circkit_amd
+    from circkit_amd import uniq as U
+    from circkit_amd import workloads as W
     ctx = circkit_amd.Context(local_rank)
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
 
-    N, L = args.records, args.length
+    config5 = args.workload == "canonicalize" and world == 8 and args.records is None and args.length == 1000
+    N = args.records if args.records is not None else (12_500_000 if config5 else 10_000_000)
+    L = args.length
     if args.workload == "mixed":
         # config 4: lengths with P(L) ~ 1/L on [200, 20000] (log-uniform), seed 45
-        N = min(N, 1_000_000)
-        g = torch.Generator(device="cpu").manual_seed(45 + rank)
-        u = torch.rand(N, generator=g, dtype=torch.float64)
-        lens = torch.exp(np.log(200.0) + u * (np.log(20000.0) - np.log(200.0))).to(torch.int64)
-        offs = torch.zeros(N + 1, dtype=torch.int64)
-        offs[1:] = torch.cumsum(lens, 0)
+        N = args.records if args.records is not None else 1_000_000
+        offs = W.log_uniform_offsets(N, 45 + rank)
         total = int(offs[-1])
         d_off = offs.to(dev)
+        d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+        ctx.synth_fill_device(45, rank * total, total, d_bytes)
     else:
+        # global record index keeps every rank's shard distinct: record g of the job = bases [g*L, (g+1)*L) of seed 42
         total = N * L
-        d_off = torch.empty(N + 1, dtype=torch.int64, device=dev)
-        ctx.fixed_offsets_device(0, L, N, d_off)
-    d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+        d_bytes, d_off = W.fixed_length(ctx, dev, N, L, 42, rank * N)
     d_out = torch.empty(total + 64, dtype=torch.uint8, device=dev)
-    # global base index keeps every rank's shard distinct: record g of the job = bases [g*L, (g+1)*L)
-    ctx.synth_fill_device(42 if args.workload != "mixed" else 45, rank * total, total, d_bytes)
-    d_hash = d_fs = None
+    if args.n_frac > 0:
+        W.sprinkle_n(d_bytes, total, args.n_frac, 46 + rank, dev)
+    d_hash = None
     if args.workload == "uniq":
-        # config 3: the second half of the shard = uniformly chosen records of the first half, rotated by a
-        # uniform k and reverse-complemented with p = 0.5; then the whole shard is shuffled (seeds 43/44)
-        half = N // 2
-        gen = torch.Generator(device=dev).manual_seed(43 + rank)
-        lut = torch.arange(256, dtype=torch.uint8, device=dev)
-        for a_, b_ in zip(b"ACGT", b"TGCA"):
-            lut[a_] = b_
-        view = d_bytes[:N * L].view(N, L)
-        col = torch.arange(L, device=dev)
-        for s0 in range(half, N, 500_000):
-            m = min(500_000, N - s0)
-            src = torch.randint(0, half, (m,), generator=gen, device=dev)
-            k = torch.randint(0, L, (m, 1), generator=gen, device=dev)
-            rows = torch.gather(view[src], 1, (col.unsqueeze(0) + k) % L)
-            flip = torch.rand(m, generator=gen, device=dev) < 0.5
-            rows[flip] = lut[rows[flip].flip(1).long()]
-            view[s0:s0 + m] = rows
-        perm = torch.randperm(N, generator=torch.Generator(device=dev).manual_seed(44 + rank), device=dev)
-        for c0 in range(0, L, 100):                       # shuffle records column block by column block (bounded temp)
-            view[:, c0:c0 + 100] = view[perm, c0:c0 + 100]
+        W.plant_duplicates(d_bytes, N, L, dev, 43 + rank, 44 + rank)          # config 3
         d_hash = torch.empty(N, dtype=torch.int64, device=dev)
-        d_fs = torch.empty(N, dtype=torch.int64, device=dev)
-        del view, perm
     torch.cuda.synchronize()
+
+    table = U.DeviceTable(ctx)
+    state = {}
 
     def step():
         if args.workload == "uniq":
-            # canonical bytes + XXH3 + first-seen table: what `circkit uniq --canonicalize` computes per batch
+            # what `circkit uniq --canonicalize` computes per batch: canonical bytes + XXH3, then the first-seen
+            # resolution -- the ctx table on one GPU, the hash-range exchange over RCCL on several
             ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out, out_xxh3=d_hash)
-            ctx.uniq_reset(N)
-            ctx.uniq_insert_device(d_hash, N, rank * N)
-            ctx.uniq_lookup_device(d_hash, N, d_fs)
+            state["fs"], state["keep"] = U.first_seen(table, d_hash, base_index=rank * N, exchange=args.exchange,
+                                                      force_exchange=force_dist)
         else:
             ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out)
 
@@ -152,74 +141,115 @@ def main():
     unprocessed = ctx.batch_status()
     if unprocessed:
         raise SystemExit("%d records were not processed" % unprocessed)
+    unique_global = None
+    if args.workload == "uniq":
+        table.check()
+        u = state["keep"].sum().to(torch.int64)
+        if use_dist:
+            dist.all_reduce(u)
+        unique_global = int(u.item())
+        if L >= 64 and unique_global != world * (N - N // 2):        # 1 kb random records collide with negligible probability
+            raise SystemExit("uniq kept %d records, expected %d" % (unique_global, world * (N - N // 2)))
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    result = None
     if rank == 0:
         seq_per_s = world * N * args.steps / dt
         algo_bytes = 2 * total + 8 * N                 # read L + write L per record + one u64 offset
         if args.workload == "uniq":
             algo_bytes += 8 * N + 32 * N               # + u64 hash per record + table insert/lookup (key + value each)
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        nvar = ", %g %% of the bases replaced by N" % (100 * args.n_frac) if args.n_frac > 0 else ""
+        if args.workload == "canonicalize":
+            metric = "canonicalize sequences/sec (%s x %d b synthetic FASTA payload)" % (
+                "10M" if N == 10_000_000 else "100M over 8 GPUs" if config5 else "%d per GPU" % N, L)
+            wl = "canonicalize, %d records x %d b per GPU%s, uniform ACGT seed 42%s, device-resident CSR (%s)" % (
+                N, L, ", 100M records in total" if config5 else "", nvar,
+                "BASELINE configs[4]" if config5 else "BASELINE configs[1]" if (N, L) == (10_000_000, 1000) and not nvar else "variant of BASELINE configs[1]")
+            kernel = "canon_stream_kernel<StreamCfg<16,2,1,1>,false,false>" if not nvar else "canon_stream_kernel + canon_rescue_kernel"
+            par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
+        elif args.workload == "uniq":
+            metric = "uniq sequences/sec (%d x %d b per GPU, ~50%% rotational/strand duplicates)" % (N, L)
+            wl = ("uniq --canonicalize, %d records x %d b per GPU, half are rotated / reverse-complemented copies, shuffled "
+                  "(BASELINE configs[2])" % (N, L))
+            kernel = "canon_stream_kernel<StreamCfg<16,2,1,1>,true,false> + uniq_insert_kernel + uniq_lookup_kernel"
+            par = ("records sharded over %d GPU(s); first-seen resolved by one hash-range all-to-all over RCCL (exchange=%s)"
+                   % (world, args.exchange)) if use_dist else "1 GPU: the ctx hash table, no collective"
+        else:
+            metric = "canonicalize sequences/sec (%d records, 200b-20kb log-uniform lengths)" % N
+            wl = "canonicalize, %d records, lengths log-uniform on [200, 20000], %d bases per GPU%s (BASELINE configs[3])" % (N, total, nvar)
+            kernel = "canon_rescue_kernel + canon_kernel tiers (whole step; per-kernel split in profiles/)"
+            par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
+        traffic, traffic_source = pmc_traffic("%s %d x %d" % (args.workload, N, L) + (" n%g" % args.n_frac if nvar else ""))
         result = {
-            "metric": {"canonicalize": "canonicalize sequences/sec (10M x 1kb synthetic FASTA payload)",
-                       "uniq": "uniq sequences/sec (10M x 1kb, ~50% rotational/strand duplicates)",
-                       "mixed": "canonicalize sequences/sec (1M records, 200b-20kb log-uniform lengths)"}[args.workload],
-            "value": seq_per_s,
-            "unit": "sequences/s",
+            "metric": metric, "value": seq_per_s, "unit": "sequences/s",
             "gbases_per_s": world * total * args.steps / dt / 1e9,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": {"canonicalize": "canonicalize, %d records x %d b per GPU, uniform ACGT seed 42, "
-                                                    "device-resident CSR (BASELINE configs[1])" % (N, L),
-                                    "uniq": "uniq --canonicalize, %d records x %d b per GPU, half are rotated / reverse-"
-                                            "complemented copies, shuffled (BASELINE configs[2])" % (N, L),
-                                    "mixed": "canonicalize, %d records, lengths log-uniform on [200, 20000], %d bases per "
-                                             "GPU (BASELINE configs[3])" % (N, total)}[args.workload],
-                       "records_per_gpu": N, "record_len": L,
-                       "parallelism": "records sharded over %d GPU(s), no data-path collective" % world},
+            "config": {"workload": wl, "records_per_gpu": N, "records_total": world * N,
+                       "record_len": L if args.workload != "mixed" else "200..20000 (mean %d)" % (total // N),
+                       "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic(N, L) if args.workload == "canonicalize" else None,
-                         "kernel": "canon_stream_kernel", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
         }
-        if args.workload == "uniq":
-            result["unique_records"] = int((d_fs == torch.arange(rank * N, rank * N + N, device=dev)).sum().item())
-        if world == 1 and not args.no_cpu and args.workload == "canonicalize":
-            from oracle import oracle as O
-            S = min(args.cpu_sample, N)
-            h_in = d_bytes[:S * L].cpu().numpy()
-            h_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(L)
-            cores = min(len(os.sched_getaffinity(0)), 16)
-            O.lib()
-            c0 = time.perf_counter()
-            h_out, _ = O.canonicalize_batch(h_in, h_off, True, False, threads=cores)
-            cdt = time.perf_counter() - c0
-            same = bool(np.array_equal(h_out, d_out[:S * L].cpu().numpy()))
-            S1 = min(S, 100_000)                    # the same restatement on ONE core, smaller sample
-            c1 = time.perf_counter()
-            O.canonicalize_batch(h_in[:S1 * L], h_off[:S1 + 1], True, False, threads=1)
-            one_core = S1 / (time.perf_counter() - c1)
-            result["cpu_baseline"] = {
-                "value": S / cdt, "unit": "sequences/s", "cores": cores, "host_cores_visible": len(os.sched_getaffinity(0)),
-                "kind": "port", "one_core_value": one_core,
-                "sample": "first %d records of the same device-generated batch; C restatement of the reference "
-                          "path (linear-time byte-indexed Duval variant, faster than the reference's O(n^2) "
-                          "chars().nth() loop), %d pthreads" % (S, cores),
-                "gpu_output_matches": same,
-            }
-            if not same:
+        if unique_global is not None:
+            result["unique_records"] = unique_global
+        if world == 1 and not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state)
+            if not result["cpu_baseline"]["gpu_output_matches"]:
                 print(json.dumps(result))
                 raise SystemExit("GPU output differs from the CPU oracle on the sample")
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
     ctx.close()
+
+
+def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
+    """The oracle (C restatement of the reference path) on EVERY host core this process may use, on a bounded sample
+    of the same device-generated batch, next to the same restatement on one core; the GPU's output on the sample is
+    compared byte for byte (uniq: also the first-seen indices)."""
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    S = min(N, args.cpu_sample if args.cpu_sample is not None else max(200_000, 20_000 * cores))
+    if args.workload == "mixed":
+        S = min(S, 100_000)                       # ~3.6 kb per record on average
+        h_off = d_off[:S + 1].cpu().numpy().astype(np.uint64)
+    else:
+        h_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(L)
+    nb = int(h_off[-1])
+    h_in = d_bytes[:nb].cpu().numpy()
+    O.lib()
+    want_hash = args.workload == "uniq"
+    c0 = time.perf_counter()
+    h_out, h_hash = O.canonicalize_batch(h_in, h_off, True, want_hash, threads=cores)
+    fs = O.uniq_first_seen(h_hash) if want_hash else None          # single thread, as the reference's main-thread closure
+    cdt = time.perf_counter() - c0
+    same = bool(np.array_equal(h_out, d_out[:nb].cpu().numpy()))
+    if want_hash:
+        # first-seen over the whole batch restricted to the first S records = first-seen of the sample alone
+        same = same and bool(np.array_equal(fs.astype(np.int64), state["fs"][:S].cpu().numpy().astype(np.int64)))
+    S1 = min(S, 100_000 if args.workload != "mixed" else 20_000)    # the same restatement on ONE core, smaller sample
+    c1 = time.perf_counter()
+    _, hh = O.canonicalize_batch(h_in[:int(h_off[S1])], h_off[:S1 + 1], True, want_hash, threads=1)
+    if want_hash:
+        O.uniq_first_seen(hh)
+    one_core = S1 / (time.perf_counter() - c1)
+    what = {"canonicalize": "normalize-free canonicalize", "uniq": "canonicalize + XXH3-64 on all cores, then the first-seen map on one "
+            "thread (the reference's main-thread closure)", "mixed": "canonicalize"}[args.workload]
+    return {
+        "value": S / cdt, "unit": "sequences/s", "cores": cores, "host_cores_visible": cores,
+        "kind": "port", "one_core_value": one_core,
+        "sample": "first %d records (%d bases) of the same device-generated batch; C restatement of the reference path: %s "
+                  "(linear-time byte-indexed Duval variant, faster than the reference's O(n^2) chars().nth() loop), %d pthreads; "
+                  "one_core_value on the first %d records" % (S, nb, what, cores, S1),
+        "gpu_output_matches": same,
+    }
 
 
 if __name__ == "__main__":

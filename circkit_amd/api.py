@@ -30,6 +30,8 @@ SIGNATURES = {
     "circkit_ctx_synchronize": (_i, [_vp]),
     "circkit_ctx_last_kernel_ms": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "circkit_ctx_batch_status": (_i, [_vp, ctypes.POINTER(_u32)]),
+    "circkit_ctx_set_long_record_scratch": (_i, [_vp, _u64]),
+    "circkit_ctx_last_batch_mode": (_i, [_vp, ctypes.POINTER(_u32)]),
     "circkit_canonicalize_batch_device": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "circkit_lmsr_batch_device": (_i, [_vp, _vp, _vp, _u64, _vp, _vp]),
     "circkit_xxh3_batch_device": (_i, [_vp, _vp, _vp, _u64, _vp]),
@@ -44,6 +46,7 @@ SIGNATURES = {
     "circkit_uniq_insert_device": (_i, [_vp, _vp, _u64, _u64]),
     "circkit_uniq_insert_pairs_device": (_i, [_vp, _vp, _vp, _u64]),
     "circkit_uniq_lookup_device": (_i, [_vp, _vp, _u64, _vp]),
+    "circkit_uniq_status": (_i, [_vp, ctypes.POINTER(_u32)]),
     "circkit_uniq_first_seen": (_i, [_vp, _vp, _u64, _u64, _vp]),
     "circkit_fasta_parse": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     "circkit_fasta_error": (ctypes.c_char_p, [_vp]),
@@ -153,6 +156,14 @@ class Context:
             self._check(rc)
         return n.value
 
+    def set_long_record_scratch(self, nbytes):
+        self._check(self._lib.circkit_ctx_set_long_record_scratch(self._h, int(nbytes)))
+
+    def last_batch_mode(self):
+        m = _u32(0)
+        self._check(self._lib.circkit_ctx_last_batch_mode(self._h, ctypes.byref(m)))
+        return m.value
+
     # -- device-resident batches (torch tensors on this ctx's GPU) -------------------------------
     def canonicalize_batch_device(self, d_bytes, d_offsets, n_records, out_bytes=None, out_index=None,
                                   out_strand=None, out_xxh3=None):
@@ -186,6 +197,10 @@ class Context:
 
     def uniq_lookup_device(self, d_hash, n, d_first_seen):
         self._check(self._lib.circkit_uniq_lookup_device(self._h, _ptr(d_hash), int(n), _ptr(d_first_seen)))
+
+    def uniq_status(self):
+        """Waits for the queued table work; raises CirckitError (OOM) if keys found no slot."""
+        self._check(self._lib.circkit_uniq_status(self._h, None))
 
     # -- host batches (numpy) -------------------------------------------------------------------
     def canonicalize_batch(self, data, offsets, want_bytes=True, want_index=False, want_strand=False,

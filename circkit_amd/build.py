@@ -35,7 +35,7 @@ def build_library(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> circkit_amd/libcirckit_hip.so (cross-compiles without a GPU)."""
     if not force and not _stale(LIB, _all_deps()):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-inline-asm",
            "-o", LIB] + [os.path.join(CSRC, s) for s in HIP_SOURCES]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

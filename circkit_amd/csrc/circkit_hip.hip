@@ -12,6 +12,7 @@
 #include "canon_core.h"
 #include "canon_fast.h"
 #include "canon_stream.h"
+#include "fasta_host.h"
 #ifndef CK_FAST_WPE
 #define CK_FAST_WPE 8     // min waves per SIMD the streaming kernel is compiled for (two 16-wave workgroups per CU: <= 64 VGPRs)
 #endif
@@ -82,9 +83,9 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 // also 1009..2032 (two words per lane, 2 KiB of image per record); it is used when at least one record in four is
 // such a record.  Carrying
 // the two-word path makes the one-word path ~12 % longer, hence two builds.  Who decides: the host when it has the
-// offsets (host-buffer API) or remembers the answer for this offsets array; otherwise stream_mode_kernel on the
-// device, with BOTH builds launched (the idle one's workgroups return at once, ~40 us) so that the call stays
-// asynchronous -- the answer is copied back and remembered for the next batch with the same offsets array.
+// offsets (host-buffer API); otherwise the device, for every batch anew: stream_count_kernel counts the batch's
+// lengths and every kernel derives the mode from the counters (batch_mode).  The call stays asynchronous: BOTH builds
+// are launched, the one the previous batch used with a full grid, the other with a small one.
 using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
 using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
 // The build with every output (index / strand / forward-only) needs ~100 SGPRs: at 16 waves per workgroup only one
@@ -95,8 +96,9 @@ using StreamCAux2 = ck::StreamCfg<4, 2, 2, 2>;
 
 // The ROWS = 2 build is used when at least 1 record in 4 is a 1009..2032-base one (it runs the shorter records 4-6 %
 // slower, the longer ones 1.5x faster than LDS tier A; at 15 % -- BASELINE config 4 -- it measured 2 % slower overall).
-// count[0] must be 0 on entry.
-__global__ __launch_bounds__(256) void stream_count_kernel(const uint64_t* offsets, uint64_t n, uint32_t* count)
+// count[0..1] must be 0 on entry.  The decision is taken again for EVERY batch from the batch's own offsets (an
+// earlier version remembered it per offsets pointer, which a host that reuses one offsets buffer defeats).
+__global__ __launch_bounds__(256) void stream_count_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* count)
 {
     uint32_t two = 0, lng = 0;          // records of 1009..2032 bases / longer ones (no build can stage their group)
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void stream_count_kernel(const uint64_t* offse
         two += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
         lng += len > ck::FAST2_MAX_N;
     }
+    if (ck::ballot(two | lng) == 0) return;                    // the common batch: nothing to add
     const uint64_t t2 = ck::wave_sum_u64(two), tl = ck::wave_sum_u64(lng);
     if (ck::lane_id() == 0 && t2) atomicAdd(count, (uint32_t)t2);
     if (ck::lane_id() == 0 && tl) atomicAdd(count + 1, (uint32_t)tl);
@@ -114,14 +117,21 @@ __host__ __device__ inline uint32_t stream_mode(uint64_t two, uint64_t lng, uint
 {
     return lng && lng * 8 >= n ? 3u : (two && two * 4 >= n ? 2u : 1u);
 }
+// every kernel of a batch derives the mode from the same two counters (or takes the host's answer)
+__device__ __forceinline__ uint32_t batch_mode(const uint32_t* __restrict__ counts, uint32_t host_mode, uint64_t n)
+{
+    return host_mode ? host_mode : stream_mode(counts[0], counts[1], n);
+}
 // Rescue pass (canon_stream.h): the streaming kernel's leftovers that are eligible by themselves, one wave per record.
 // A small persistent grid walks the list segments (a batch the streaming kernel handled completely leaves them
 // empty: the pass then costs a microsecond, not the dispatch of one workgroup per segment); segment s of the input
 // list yields segment s of the output list, so the tiers behind keep their geometry.
 template <bool HASH, bool AUX>
-__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, const uint32_t* mode, uint32_t host_mode)
+__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, const uint32_t* __restrict__ counts, uint32_t host_mode, uint32_t* mode_out)
 {
-    const bool all_records = (host_mode ? host_mode : *mode) == 3;       // the streaming kernel stood this batch out
+    const uint32_t mode = batch_mode(counts, host_mode, a.n_records);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
+    const bool all_records = mode == 3;                                 // the streaming kernel stood this batch out
     __shared__ uint32_t lut[256], seg_count;
     ck::fast_lut_init(lut, threadIdx.x, 256);
     ck::RescueState<HASH, AUX> st;
@@ -136,24 +146,26 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
     }
 }
 
-__global__ void stream_mode_kernel(const uint32_t* count, uint64_t n, uint32_t* mode)
-{
-    *mode = stream_mode(count[0], count[1], n);
-}
-
+// `nvb` virtual workgroups (one list segment each) are walked by the launched ones: the build the host expects to
+// match the batch is launched with one workgroup per virtual one, the other build with a small grid -- its
+// workgroups normally return at once, and take the whole batch when the expectation was wrong.
 template <class StreamC, bool HASH, bool AUX>
-__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* mode)
+__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ counts,
+                                                                                                             uint32_t host_mode, uint32_t nvb)
 {
-    if (mode && *mode != (uint32_t)StreamC::ROWS) return;    // the other build has this batch (mode == nullptr: the host chose)
+    if (batch_mode(counts, host_mode, a.n_records) != (uint32_t)StreamC::ROWS) return;    // the other build (or none) has this batch
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + 256;
     ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
-    if (threadIdx.x == 0) *blk_count = 0;
-    __syncthreads();
-    ck::canon_stream_wave_loop<StreamC, HASH, AUX>(a, lut, lds, blk_count, blockIdx.x, gridDim.x);
-    __syncthreads();
-    if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
+    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        if (threadIdx.x == 0) *blk_count = 0;
+        __syncthreads();
+        ck::canon_stream_wave_loop<StreamC, HASH, AUX>(a, lut, lds, blk_count, vb, nvb);
+        ck::vmem_wait<0>();                              // no DMA of this virtual workgroup may land in the next one's images
+        __syncthreads();
+        if (threadIdx.x == 0) a.defer_count[vb] = *blk_count;
+    }
 }
 
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).  With `hashed` (the flags of
@@ -231,42 +243,63 @@ __global__ void fixed_offsets_kernel(uint64_t base, uint64_t len, uint64_t n, ui
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += stride) off[i] = base + i * len;
 }
 
-// uniq: open-addressing table keyed by the 64-bit hash, value = smallest global record index.
+// uniq: open-addressing table keyed by the 64-bit hash, value = smallest global record index.  One 16-byte slot
+// {key, value} per entry, so that claiming a key and folding its index touch ONE 64-byte sector (two arrays: two
+// random DRAM accesses per key).  Slot [mask + 1] keeps the value of the key that equals the EMPTY marker.
 constexpr uint64_t UNIQ_EMPTY = ~0ull;
+struct __attribute__((aligned(16))) UniqSlot { unsigned long long key, val; };
 __device__ __forceinline__ uint64_t uniq_slot(uint64_t h, uint64_t mask) { return (h ^ (h >> 29)) & mask; }
-
-// value of key i: index[i] when given (pairs gathered from other ranks), else base + i (a shard in input order)
-__global__ void uniq_insert_kernel(const uint64_t* hash, const uint64_t* index, uint64_t n, uint64_t base, unsigned long long* keys,
-                                   unsigned long long* vals, uint64_t mask, uint32_t* status)
+__device__ __forceinline__ UniqSlot uniq_peek(const UniqSlot* p)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint64_t h = hash[i];
-        const unsigned long long v = index ? index[i] : base + i;
-        if (h == UNIQ_EMPTY) { atomicMin(&vals[mask + 1], v); continue; }
-        uint64_t s = uniq_slot(h, mask);
-        uint64_t probes = 0;
-        for (;;) {
-            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
-            if (old == UNIQ_EMPTY || old == h) { atomicMin(&vals[s], v); break; }
-            s = (s + 1) & mask;
-            if (++probes > mask) { atomicAdd(status, 1u); break; }   // table full
+    typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+    const v2 v = *reinterpret_cast<const v2*>(p);          // one global_load_dwordx4
+    return UniqSlot{ v.x, v.y };
+}
+// Folds (h, v) into the table.  The scattered device-scope atomics are the limiter (~20 G/s chip-wide, measured:
+// 10M keys x CAS + min = 1.08 ms), so a plain 16-byte read goes first: a key that is already there with a smaller
+// value -- the later copies of a duplicated record, since threads take records roughly in index order -- needs no
+// atomic at all, a present key one, a new key two.  The read may be stale; it is only trusted where staleness cannot
+// hurt: a key, once written, never changes, and a value only decreases.
+__device__ __forceinline__ bool uniq_fold(UniqSlot* t, uint64_t mask, uint64_t h, unsigned long long v)
+{
+    if (h == UNIQ_EMPTY) { atomicMin(&t[mask + 1].val, v); return true; }
+    uint64_t s = uniq_slot(h, mask), probes = 0;
+    for (;;) {
+        const UniqSlot cur = uniq_peek(t + s);
+        if (cur.key == h) {
+            if (cur.val > v) atomicMin(&t[s].val, v);
+            return true;
         }
+        if (cur.key == UNIQ_EMPTY) {
+            const unsigned long long old = atomicCAS(&t[s].key, (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
+            if (old == UNIQ_EMPTY || old == h) { atomicMin(&t[s].val, v); return true; }
+        }
+        s = (s + 1) & mask;
+        if (++probes > mask) return false;                  // table full
     }
 }
 
-__global__ void uniq_lookup_kernel(const uint64_t* hash, uint64_t n, const unsigned long long* keys,
-                                   const unsigned long long* vals, uint64_t mask, uint64_t* first_seen)
+// value of key i: index[i] when given (pairs gathered from other ranks), else base + i (a shard in input order)
+__global__ __launch_bounds__(256) void uniq_insert_kernel(const uint64_t* __restrict__ hash, const uint64_t* __restrict__ index, uint64_t n, uint64_t base,
+                                                          UniqSlot* t, uint64_t mask, uint32_t* status)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (!uniq_fold(t, mask, hash[i], index ? index[i] : base + i)) atomicAdd(status, 1u);
+}
+
+__global__ __launch_bounds__(256) void uniq_lookup_kernel(const uint64_t* __restrict__ hash, uint64_t n, const UniqSlot* __restrict__ t, uint64_t mask,
+                                                          uint64_t* first_seen)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t h = hash[i];
-        if (h == UNIQ_EMPTY) { first_seen[i] = vals[mask + 1]; continue; }
+        if (h == UNIQ_EMPTY) { first_seen[i] = t[mask + 1].val; continue; }
         uint64_t s = uniq_slot(h, mask), probes = 0, r = UNIQ_EMPTY;
         for (;;) {
-            const uint64_t k = keys[s];
-            if (k == h) { r = vals[s]; break; }
-            if (k == UNIQ_EMPTY || ++probes > mask) break;
+            const UniqSlot cur = uniq_peek(t + s);
+            if (cur.key == h) { r = cur.val; break; }
+            if (cur.key == UNIQ_EMPTY || ++probes > mask) break;
             s = (s + 1) & mask;
         }
         first_seen[i] = r;
@@ -274,27 +307,23 @@ __global__ void uniq_lookup_kernel(const uint64_t* hash, uint64_t n, const unsig
 }
 
 // moves every (key, smallest index) entry of an old table into a bigger one
-__global__ void uniq_rehash_kernel(const unsigned long long* okeys, const unsigned long long* ovals, uint64_t oslots,
-                                   unsigned long long* keys, unsigned long long* vals, uint64_t mask)
+__global__ __launch_bounds__(256) void uniq_rehash_kernel(const UniqSlot* __restrict__ old, uint64_t oslots, UniqSlot* t, uint64_t mask)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < oslots; i += stride) {
-        const uint64_t h = okeys[i], v = ovals[i];
-        if (i + 1 == oslots) { if (v != UNIQ_EMPTY) atomicMin(&vals[mask + 1], (unsigned long long)v); continue; }   // the EMPTY-key slot
-        if (h == UNIQ_EMPTY) continue;
-        uint64_t s = uniq_slot(h, mask);
-        for (;;) {
-            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
-            if (old == UNIQ_EMPTY || old == h) { atomicMin(&vals[s], (unsigned long long)v); break; }
-            s = (s + 1) & mask;
-        }
+        const UniqSlot e = uniq_peek(old + i);
+        if (i + 1 == oslots) { if (e.val != UNIQ_EMPTY) atomicMin(&t[mask + 1].val, e.val); continue; }   // the EMPTY-key slot
+        if (e.key != UNIQ_EMPTY) (void)uniq_fold(t, mask, e.key, e.val);
     }
 }
 
-__global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long long v)
+// every slot = {EMPTY, EMPTY}: 16 bytes per thread and trip
+__global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t slots)
 {
+    typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride)
+        *reinterpret_cast<v2*>(t + i) = v2{ UNIQ_EMPTY, UNIQ_EMPTY };
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -304,7 +333,7 @@ __global__ void fill_u64_kernel(unsigned long long* p, uint64_t n, unsigned long
 //   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~21 kb: covers BASELINE config 4's 20 kb tail
 //   C: 1 wave x 39 KiB (4 per CU)                             2-bit up to ~63 kb, byte-mode up to ~18 kb
 //   D: 1 wave x 158 KiB (the whole CU)                        2-bit up to ~258 kb, byte-mode up to ~76 kb
-//   beyond: canon_global_kernel, the same code over a global-memory scratch (finish_giants)
+//   beyond: canon_global_kernel, the same code over slices of a global-memory scratch (two more stages of every batch)
 #ifndef CK_RESCUE_BPC
 #define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
 #endif
@@ -348,19 +377,17 @@ struct circkit_ctx {
     uint64_t cap_bytes = 0, cap_rec = 0;
     uint8_t* d_scratch = nullptr; uint64_t cap_scratch = 0;   // canonical bytes of hash-only batches
     uint8_t* d_hashed = nullptr; uint64_t cap_hashed = 0;     // per record: hash already written by the streaming kernel
-    // records the last LDS tier could not hold: finished by finish_giants() at the next synchronisation point
-    ck::CanonArgs last_args{};
-    uint64_t* last_hash = nullptr;
-    unsigned giant_nseg = 0; uint32_t giant_seg_cap = 0;
-    bool giants_pending = false;
-    // which build of the streaming kernel took the batch with this offsets array (0 = not known yet)
-    const void* mode_key = nullptr; uint64_t mode_key_n = 0;
-    uint32_t* h_mode = nullptr;          // pinned; written by the device-side decision's copy-back
+    // records beyond the last LDS tier run the same per-record code over slices of this global-memory scratch
+    // (grow-only; the device API allocates the default on first use, the host API sizes it for the batch's longest record)
+    uint32_t* d_gscratch = nullptr; uint64_t cap_gscratch = 0;    // bytes
+    uint64_t gscratch_default = 256ull << 20;
+    // the previous batch's mode (1 / 2 / 3, see stream_mode): only picks which build gets the full-size grid
+    uint32_t* h_mode = nullptr;          // pinned; d_counters[5] of the most recent batch, copied back behind it
     hipEvent_t mode_ev = nullptr;
     bool mode_pending = false;
-    uint32_t mode_known = 0;
+    uint32_t mode_hint = 1;
     // uniq table
-    unsigned long long *d_keys = nullptr, *d_vals = nullptr;
+    UniqSlot* d_table = nullptr;         // [uniq_mask + 2]
     uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
 };
 
@@ -401,21 +428,40 @@ int ensure_lists(circkit_ctx* c, uint64_t entries, uint64_t segs)
     return CIRCKIT_OK;
 }
 
+int ensure_gscratch(circkit_ctx* c, uint64_t bytes)
+{
+    if (bytes <= c->cap_gscratch) return CIRCKIT_OK;
+    if (c->d_gscratch) { (void)hipFree(c->d_gscratch); c->d_gscratch = nullptr; c->cap_gscratch = 0; }
+    CK_HIP(c, hipMalloc(&c->d_gscratch, bytes));
+    c->cap_gscratch = bytes;
+    return CIRCKIT_OK;
+}
+
+// LDS dwords (or scratch dwords) the byte-wide mode needs for a record of n symbols: the largest of the three modes
+// (ck::need_dw<8>), with 64 dwords of slack
+inline uint64_t worst_case_dw(uint64_t n) { return 2 * ((n + 3) / 4 + 2) + (n + 31) / 32 + 1 + 64; }
+constexpr uint64_t GSLICE1_DW = 1ull << 20;     // stage 1 of the global-scratch pass: up to 64 waves x 4 MiB
+
+// Enqueues one batch: every kernel, nothing else -- no host-side follow-up is needed once the stream has run them
+// (records beyond the on-chip tiers included: the last two stages take them in a global-memory scratch).
+// host_mode: 1 / 2 / 3 when the host has seen the offsets (stream_mode), 0 = the device decides.
 int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out,
                  uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags, uint32_t host_mode = 0)
 {
     if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
-    // launch geometry: G workgroups of 4 waves for the streaming kernel and tier A (segment b of a list belongs to
-    // workgroup b); the one-wave tiers B, C take 4 segments per workgroup each; tier D is the end of the line
+    // launch geometry: G virtual workgroups for the streaming kernel, the rescue pass and tier A (segment b of a list
+    // belongs to workgroup b); the one-wave tiers C, D take several segments per workgroup each
     const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
     const uint64_t per_step = aux ? StreamCAux::GROUP : StreamC::GROUP;    // records a workgroup takes per iteration
     const uint64_t blocks = (n + per_step - 1) / per_step;
     const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
     const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
-    int rc = ensure_lists(c, (uint64_t)G * cap + 256ull * cap, G);
+    // + 1024 segments of slack: a stage that merges k segments per workgroup addresses up to k - 1 segments past the end
+    int rc = ensure_lists(c, (uint64_t)G * cap + 1024ull * cap, G < 256u ? 256u : G);
     if (rc) return rc;
+    if (!c->d_gscratch && (rc = ensure_gscratch(c, c->gscratch_default))) return rc;
     if (d_hash && !d_out) {
         // hash-only (uniq without --canonicalize): the canonical bytes go to a ctx-owned scratch the hash kernel
         // reads back.  Its size is offsets[n], fetched from the device (one small synchronous copy).
@@ -438,6 +484,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         }
         CK_HIP(c, hipMemsetAsync(c->d_hashed, 0, n, c->stream));
     }
+    // d_counters: [3] records nothing could take, [4] uniq table overflow, [5] the batch's mode, [6..7] length counts
     CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
@@ -448,40 +495,33 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
-    uint32_t stream_rows = 0;       // 1 / 2 / 3 when the host knows the batch's mode (see stream_mode), 0 = the device word decides
+    const uint32_t* counts = c->d_counters + 6;
     {
         // three builds of the streaming kernel: canonical bytes only (the headline), + fused XXH3 (uniq), and the
-        // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr)
-        const dim3 grid(G), block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64);
-        // which build: 1 / 2 when the host knows, 0 = decided on the device (both launched)
-        uint32_t rows = host_mode;
-        if (!rows) {
-            if (c->mode_pending && c->mode_key == (const void*)d_offsets && c->mode_key_n == n) {
-                if (hipEventQuery(c->mode_ev) == hipSuccess) { c->mode_known = *c->h_mode; c->mode_pending = false; }
-                else (void)hipGetLastError();          // hipErrorNotReady is not an error of this call
-            }
-            if (c->mode_key == (const void*)d_offsets && c->mode_key_n == n && !c->mode_pending) rows = c->mode_known;
-        }
-        const uint32_t* mode = nullptr;
-        if (!rows) {
-            mode = c->d_counters + 5;
+        // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr);
+        // each for ROWS = 1 and ROWS = 2.  The host's answer launches exactly one of the two; a device-side decision
+        // launches both, full-size where the previous batch's mode says it will run.
+        if (!host_mode) {
+            if (c->mode_pending && hipEventQuery(c->mode_ev) == hipSuccess) { c->mode_hint = *c->h_mode; c->mode_pending = false; }
+            else (void)hipGetLastError();          // hipErrorNotReady is not an error of this call
             CK_HIP(c, hipMemsetAsync(c->d_counters + 6, 0, 8, c->stream));
-            hipLaunchKernelGGL(stream_count_kernel, dim3(N_CU), dim3(256), 0, c->stream, d_offsets, n, c->d_counters + 6);
-            hipLaunchKernelGGL(stream_mode_kernel, dim3(1), dim3(1), 0, c->stream, (const uint32_t*)(c->d_counters + 6), n, c->d_counters + 5);
-            CK_HIP(c, hipMemcpyAsync(c->h_mode, c->d_counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
-            CK_HIP(c, hipEventRecord(c->mode_ev, c->stream));
-            c->mode_key = d_offsets; c->mode_key_n = n; c->mode_pending = true; c->mode_known = 0;
+            hipLaunchKernelGGL(stream_count_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_offsets, n, c->d_counters + 6);
         }
-        stream_rows = rows;
-        if (rows != 2 && rows != 3) {
-            if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux, true, true>), grid, block_aux, 0, c->stream, a, mode);
-            else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC, true, false>), grid, block, 0, c->stream, a, mode);
-            else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false>), grid, block, 0, c->stream, a, mode);
-        }
-        if (rows != 1 && rows != 3) {
-            if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux2, true, true>), grid, block_aux, 0, c->stream, a, mode);
-            else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC2, true, false>), grid, block, 0, c->stream, a, mode);
-            else hipLaunchKernelGGL((canon_stream_kernel<StreamC2, false, false>), grid, block, 0, c->stream, a, mode);
+        const uint32_t expect = host_mode ? host_mode : c->mode_hint;
+        const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
+        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64);
+        for (uint32_t rows = 1; rows <= 2; ++rows) {
+            if (host_mode && host_mode != rows) continue;
+            const dim3 grid(expect == rows ? G : small);
+            if (rows == 1) {
+                if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux, true, true>), grid, block_aux, 0, c->stream, a, counts, host_mode, G);
+                else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC, true, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
+                else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
+            } else {
+                if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux2, true, true>), grid, block_aux, 0, c->stream, a, counts, host_mode, G);
+                else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC2, true, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
+                else hipLaunchKernelGGL((canon_stream_kernel<StreamC2, false, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
+            }
         }
     }
     unsigned nseg = G;              // segments / capacity of the list the next stage consumes
@@ -492,10 +532,13 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.list = c->d_lists[0]; a.list_count = c->d_seg_counts;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = 1;
         a.defer_list = c->d_lists[1]; a.defer_count = c->d_seg_counts + c->seg_alloc; a.out_seg_cap = seg_cap;
-        const uint32_t* mode = c->d_counters + 5;
-        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a, mode, stream_rows);
-        else if (d_hash) hipLaunchKernelGGL((canon_rescue_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a, mode, stream_rows);
-        else hipLaunchKernelGGL((canon_rescue_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a, mode, stream_rows);
+        uint32_t* mode_out = c->d_counters + 5;
+        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+        else if (d_hash) hipLaunchKernelGGL((canon_rescue_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+        else hipLaunchKernelGGL((canon_rescue_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+        CK_HIP(c, hipMemcpyAsync(c->h_mode, mode_out, 4, hipMemcpyDeviceToHost, c->stream));
+        CK_HIP(c, hipEventRecord(c->mode_ev, c->stream));
+        c->mode_pending = true;
     }
     for (int t = 0; t < N_TIERS; ++t) {
         const bool last = t == N_TIERS - 1;
@@ -503,7 +546,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const unsigned grid = (nseg + spb - 1) / spb;
         a.list = c->d_lists[t + 1]; a.list_count = c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb;
-        // the last tier's leftovers go into the first list (long consumed by now): finish_giants() picks them up
+        // the last tier's leftovers go into the first list (long consumed by now): the global-scratch stages pick them up
         a.defer_list = last ? c->d_lists[0] : c->d_lists[t + 2];
         a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 2) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
@@ -513,9 +556,26 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         nseg = grid;
         seg_cap = spb * seg_cap;
     }
-    c->last_args = a; c->last_hash = d_hash;
-    c->giant_nseg = nseg; c->giant_seg_cap = seg_cap;
-    c->giants_pending = true;
+    {
+        // Records no LDS tier can hold (2-bit beyond ~258 kb, byte-mode beyond ~76 kb): the same code, one wave per
+        // record, with a slice of the global scratch in place of the LDS slice.  Stage 1: up to 64 waves x 4 MiB
+        // (2-bit records up to ~6.7 Mb); stage 2: one wave with the whole scratch (256 MiB by default: 2-bit up to
+        // ~430 Mb, bytes up to ~126 MB; see circkit_ctx_set_long_record_scratch).  Beyond: counted in status[0].
+        const uint64_t cap_dw = c->cap_gscratch / 4;
+        const uint64_t slice1 = cap_dw < GSLICE1_DW ? cap_dw : GSLICE1_DW;
+        const unsigned max_w1 = (unsigned)(cap_dw / slice1 < 64 ? cap_dw / slice1 : 64);
+        const unsigned spb1 = (nseg + max_w1 - 1) / max_w1, w1 = (nseg + spb1 - 1) / spb1;
+        a.list = c->d_lists[0]; a.list_count = c->d_seg_counts;
+        a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb1;
+        a.defer_list = c->d_lists[1]; a.defer_count = c->d_seg_counts + c->seg_alloc; a.out_seg_cap = spb1 * seg_cap;
+        a.slice_dw = (uint32_t)slice1;
+        hipLaunchKernelGGL(canon_global_kernel, dim3(w1), dim3(64), 0, c->stream, a, c->d_gscratch);
+        a.list = c->d_lists[1]; a.list_count = c->d_seg_counts + c->seg_alloc;
+        a.in_nseg = w1; a.in_seg_cap = spb1 * seg_cap; a.segs_per_block = w1;
+        a.defer_list = nullptr; a.defer_count = nullptr; a.out_seg_cap = 0;
+        a.slice_dw = (uint32_t)(cap_dw < 0xFFFFFFFFull ? cap_dw : 0xFFFFFFFFull);
+        hipLaunchKernelGGL(canon_global_kernel, dim3(1), dim3(64), 0, c->stream, a, c->d_gscratch);
+    }
     if (d_hash) {
         hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed);
     }
@@ -525,70 +585,32 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     return CIRCKIT_OK;
 }
 
-// Records beyond the largest LDS tier, found after the batch's kernels have run: read the last tier's leftover list
-// back, size a global scratch for them and run canon_global_kernel (and the hash of their canonical bytes).  Called
-// at every point where the library synchronises with the batch; blocking, and rare by construction.
-int finish_giants(circkit_ctx* c)
+// One record through the host API (the lib-crate mirrors circkit_lmsr_index / _lmsr / _canonicalize): a single launch
+// of the general per-record kernel with the smallest slice that holds the record in any mode, instead of the batch
+// pipeline's dozen launches.
+int launch_single(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t len, uint8_t* d_out, uint32_t* d_idx,
+                  uint8_t* d_strand, uint64_t* d_hash, uint32_t flags)
 {
-    if (!c->giants_pending) return CIRCKIT_OK;
-    c->giants_pending = false;
-    CK_HIP(c, hipStreamSynchronize(c->stream));
-    std::vector<uint32_t> counts(c->giant_nseg);
-    CK_HIP(c, hipMemcpy(counts.data(), c->d_seg_counts, counts.size() * 4, hipMemcpyDeviceToHost));
-    std::vector<uint32_t> recs;
-    for (unsigned sgm = 0; sgm < c->giant_nseg; ++sgm) {
-        if (!counts[sgm]) continue;
-        const size_t at = recs.size();
-        recs.resize(at + counts[sgm]);
-        CK_HIP(c, hipMemcpy(recs.data() + at, c->d_lists[0] + (uint64_t)sgm * c->giant_seg_cap, counts[sgm] * 4ull, hipMemcpyDeviceToHost));
-    }
-    if (recs.empty()) return CIRCKIT_OK;
-    ck::CanonArgs a = c->last_args;
-    // slice = what the 8-bit mode needs for the longest of them (the largest of the three modes)
-    uint64_t max_len = 0;
-    for (uint32_t r : recs) {
-        uint64_t o[2];
-        CK_HIP(c, hipMemcpy(o, a.offsets + r, 16, hipMemcpyDeviceToHost));
-        if (o[1] - o[0] > max_len) max_len = o[1] - o[0];
-    }
-    uint32_t leftover = 0;
-    if (max_len >> 31) {
-        // cyclic symbol positions (p < 2n) are 32-bit throughout: 2 Gi symbols is the limit of the format
-        leftover = (uint32_t)recs.size();
+    ck::CanonArgs a{};
+    a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = 1;
+    a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr; a.hashed = nullptr;
+    a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
+    CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    const uint64_t need = worst_case_dw(len);
+    int t = 0;
+    while (t < N_TIERS && TIER_DW[t] < need) ++t;
+    if (t < N_TIERS) {
+        a.slice_dw = TIER_DW[t];
+        hipLaunchKernelGGL(canon_kernel<1>, dim3(1), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a);
     } else {
-        const uint64_t slice = 2 * ((max_len + 3) / 4 + 2) + (max_len + 31) / 32 + 1 + 64;     // ck::need_dw<8>(max_len) + slack
-        unsigned waves = (unsigned)(recs.size() < 64 ? recs.size() : 64);
-        uint32_t* scratch = nullptr;
-        while (waves && hipMalloc(&scratch, slice * 4 * waves) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; waves /= 2; }
-        if (!scratch) return fail(c, CIRCKIT_ERR_OOM, "no memory for the scratch of a %llu-symbol record", (unsigned long long)max_len);
-        uint32_t *d_list = nullptr, *d_ones = nullptr;
-        std::vector<uint32_t> ones(recs.size(), 1u);
-        hipError_t e = hipMalloc(&d_list, recs.size() * 4);
-        if (e == hipSuccess) e = hipMalloc(&d_ones, recs.size() * 4);
-        if (e == hipSuccess) e = hipMemcpy(d_list, recs.data(), recs.size() * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_ones, ones.data(), ones.size() * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemsetAsync(c->d_counters + 3, 0, 4, c->stream);
-        if (e == hipSuccess) {
-            // one record per list segment; workgroup b (one wave) takes segments [b*spb, (b+1)*spb)
-            a.list = d_list; a.list_count = d_ones; a.in_nseg = (uint32_t)recs.size(); a.in_seg_cap = 1;
-            a.segs_per_block = (uint32_t)((recs.size() + waves - 1) / waves);
-            a.defer_list = nullptr; a.defer_count = nullptr; a.out_seg_cap = 0;
-            a.slice_dw = (uint32_t)(slice < 0xFFFFFFFFull ? slice : 0xFFFFFFFFull);
-            hipLaunchKernelGGL(canon_global_kernel, dim3(waves), dim3(64), 0, c->stream, a, scratch);
-            if (c->last_hash)
-                hipLaunchKernelGGL(xxh3_list_kernel, dim3(waves), dim3(64), 0, c->stream, a.out_bytes, a.offsets, (const uint32_t*)d_list,
-                                   (uint32_t)recs.size(), c->last_hash);
-            e = hipMemcpyAsync(&leftover, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        }
-        (void)hipFree(scratch); (void)hipFree(d_list); (void)hipFree(d_ones);
-        if (e != hipSuccess) return fail(c, CIRCKIT_ERR_HIP, "long-record pass failed: %s", hipGetErrorString(e));
+        int rc = ensure_gscratch(c, need * 4);
+        if (rc) return rc;
+        a.slice_dw = (uint32_t)(need < 0xFFFFFFFFull ? need : 0xFFFFFFFFull);
+        hipLaunchKernelGGL(canon_global_kernel, dim3(1), dim3(64), 0, c->stream, a, c->d_gscratch);
     }
-    if (leftover) {
-        // keep the count where circkit_ctx_batch_status() reads it
-        CK_HIP(c, hipMemcpy(c->d_counters + 3, &leftover, 4, hipMemcpyHostToDevice));
-        return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) of 2^31 symbols or more were not processed", leftover);
-    }
+    if (d_hash) hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, d_out, d_offsets, (uint64_t)1, d_hash, (const uint8_t*)nullptr);
+    CK_HIP(c, hipGetLastError());
+    c->timed = false;
     return CIRCKIT_OK;
 }
 
@@ -637,16 +659,24 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     if (total) CK_HIP(c, hipMemcpyAsync(c->d_in, bytes, total, hipMemcpyHostToDevice, c->stream));
     CK_HIP(c, hipMemcpyAsync(c->d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     const bool need_bytes = out || hash;
-    uint64_t two_word = 0, longer = 0;                // the host has the offsets: it picks the streaming kernel's build
+    uint64_t two_word = 0, longer = 0, max_len = 0;   // the host has the offsets: it picks the streaming kernel's build
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t len = offsets[i + 1] - offsets[i];
         two_word += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
         longer += len > ck::FAST2_MAX_N;
+        max_len = len > max_len ? len : max_len;
     }
-    rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
-                      strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags, stream_mode(two_word, longer, n));
+    if (max_len >> 31) return fail(c, CIRCKIT_ERR_TOO_LONG, "a record of 2^31 symbols or more (cyclic positions are 32-bit)");
+    if (n == 1) {
+        rc = launch_single(c, c->d_in, c->d_off, max_len, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
+                           strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags);
+    } else {
+        // ...and sizes the global scratch for the longest record, whatever mode it turns out to need
+        if (worst_case_dw(max_len) > TIER_D_DW && (rc = ensure_gscratch(c, worst_case_dw(max_len) * 4))) return rc;
+        rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
+                          strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags, stream_mode(two_word, longer, n));
+    }
     if (rc) return rc;
-    if ((rc = finish_giants(c))) return rc;
     if (out && total) CK_HIP(c, hipMemcpyAsync(out, c->d_out, total, hipMemcpyDeviceToHost, c->stream));
     if (idx) CK_HIP(c, hipMemcpyAsync(idx, c->d_idx, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (strand) CK_HIP(c, hipMemcpyAsync(strand, c->d_strand, n, hipMemcpyDeviceToHost, c->stream));
@@ -705,9 +735,10 @@ int circkit_ctx_destroy(circkit_ctx* c)
     if (!c) return CIRCKIT_OK;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void* ptrs[] = { c->d_comp, c->d_counters, c->d_seg_counts, c->d_lists[0], c->d_lists[1], c->d_lists[2], c->d_lists[3], c->d_in, c->d_out, c->d_strand, c->d_off,
-                     c->d_idx, c->d_hash, c->d_keys, c->d_vals, c->d_scratch, c->d_hashed };
+    void* ptrs[] = { c->d_comp, c->d_counters, c->d_seg_counts, c->d_in, c->d_out, c->d_strand, c->d_off, c->d_idx, c->d_hash, c->d_table,
+                     c->d_scratch, c->d_hashed, c->d_gscratch };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (uint32_t* p : c->d_lists) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->mode_ev) (void)hipEventDestroy(c->mode_ev);
@@ -738,7 +769,7 @@ int circkit_ctx_synchronize(circkit_ctx* c)
     if (!c) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
     CK_HIP(c, hipStreamSynchronize(c->stream));
-    return finish_giants(c);
+    return CIRCKIT_OK;
 }
 
 int circkit_ctx_last_kernel_ms(circkit_ctx* c, float* ms)
@@ -755,11 +786,31 @@ int circkit_ctx_batch_status(circkit_ctx* c, uint32_t* n_unprocessed)
     if (!c || !n_unprocessed) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
     *n_unprocessed = 0;
-    const int rc = finish_giants(c);
-    if (rc && rc != CIRCKIT_ERR_TOO_LONG) return rc;
     CK_HIP(c, hipMemcpyAsync(n_unprocessed, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
-    return *n_unprocessed ? CIRCKIT_ERR_TOO_LONG : CIRCKIT_OK;
+    if (*n_unprocessed)
+        return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) were not processed: longer than the long-record scratch (%llu MiB, "
+                    "circkit_ctx_set_long_record_scratch) or than 2^31 symbols", *n_unprocessed, (unsigned long long)(c->cap_gscratch >> 20));
+    return CIRCKIT_OK;
+}
+
+int circkit_ctx_set_long_record_scratch(circkit_ctx* c, uint64_t bytes)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    if (bytes < (1ull << 20)) bytes = 1ull << 20;
+    c->gscratch_default = bytes;
+    CK_HIP(c, hipStreamSynchronize(c->stream));        // a batch in flight may be using the old one
+    return ensure_gscratch(c, bytes);
+}
+
+int circkit_ctx_last_batch_mode(circkit_ctx* c, uint32_t* mode)
+{
+    if (!c || !mode) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    CK_HIP(c, hipMemcpyAsync(mode, c->d_counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    return CIRCKIT_OK;
 }
 
 int circkit_canonicalize_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets,
@@ -865,21 +916,22 @@ int circkit_xxh3_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint
     return CIRCKIT_OK;
 }
 
+#ifndef CK_UNIQ_LOAD_PCT
+#define CK_UNIQ_LOAD_PCT 70       // circkit_uniq_reset sizes the table for at most this load with `expected_keys` distinct keys
+#endif
 int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
 {
     if (!c) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
     uint64_t cap = 1024;
-    while (cap < 2 * expected_keys) cap <<= 1;
-    if (cap - 1 != c->uniq_mask || !c->d_keys) {
+    while (cap * CK_UNIQ_LOAD_PCT < expected_keys * 100) cap <<= 1;
+    if (cap - 1 != c->uniq_mask || !c->d_table) {
         c->uniq_mask = 0;
         int rc;
-        if ((rc = grow(c, c->d_keys, cap + 1))) return rc;
-        if ((rc = grow(c, c->d_vals, cap + 1))) return rc;
+        if ((rc = grow(c, c->d_table, cap + 1))) return rc;
         c->uniq_mask = cap - 1;
     }
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_keys, cap + 1, (unsigned long long)UNIQ_EMPTY);
-    hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_vals, cap + 1, (unsigned long long)UNIQ_EMPTY);
+    hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_table, cap + 1);
     CK_HIP(c, hipMemsetAsync(c->d_counters + 4, 0, 4, c->stream));
     CK_HIP(c, hipGetLastError());
     c->uniq_count = 0;
@@ -893,31 +945,29 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
     if (!c || (n && (!hash || !first_seen))) return CIRCKIT_ERR_INVALID_ARG;
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    if (!c->d_keys || (c->uniq_count + n) * 2 > c->uniq_mask + 1) {
+    if (!c->d_table || (c->uniq_count + n) * 2 > c->uniq_mask + 1) {
         uint64_t cap = 1 << 16;
         while (cap < 4 * (c->uniq_count + n)) cap <<= 1;
-        unsigned long long *nk = nullptr, *nv = nullptr;
-        CK_HIP(c, hipMalloc(&nk, (cap + 1) * 8));
-        CK_HIP(c, hipMalloc(&nv, (cap + 1) * 8));
-        hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nk, cap + 1, (unsigned long long)UNIQ_EMPTY);
-        hipLaunchKernelGGL(fill_u64_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nv, cap + 1, (unsigned long long)UNIQ_EMPTY);
-        if (c->d_keys) {
-            hipLaunchKernelGGL(uniq_rehash_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_keys, c->d_vals,
-                               c->uniq_mask + 2, nk, nv, cap - 1);
-            CK_HIP(c, hipStreamSynchronize(c->stream));
-            (void)hipFree(c->d_keys); (void)hipFree(c->d_vals);
+        UniqSlot* nt = nullptr;
+        CK_HIP(c, hipMalloc(&nt, (cap + 1) * sizeof(UniqSlot)));
+        hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nt, cap + 1);
+        if (c->d_table) {
+            hipLaunchKernelGGL(uniq_rehash_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const UniqSlot*)c->d_table, c->uniq_mask + 2, nt, cap - 1);
+            const hipError_t e = hipStreamSynchronize(c->stream);
+            (void)hipFree(c->d_table); c->d_table = nullptr;
+            if (e != hipSuccess) { (void)hipFree(nt); return fail(c, CIRCKIT_ERR_HIP, "uniq table rehash failed: %s", hipGetErrorString(e)); }
         } else {
             CK_HIP(c, hipMemsetAsync(c->d_counters + 4, 0, 4, c->stream));
         }
-        c->d_keys = nk; c->d_vals = nv; c->uniq_mask = cap - 1;
+        c->d_table = nt; c->uniq_mask = cap - 1;
     }
     int rc = ensure_staging(c, 0, n);
     if (rc) return rc;
     CK_HIP(c, hipMemcpyAsync(c->d_hash, hash, n * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_hash, (const uint64_t*)nullptr, n, base_index,
-                       c->d_keys, c->d_vals, c->uniq_mask, c->d_counters + 4);
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const uint64_t*)c->d_hash, (const uint64_t*)nullptr, n, base_index,
+                       c->d_table, c->uniq_mask, c->d_counters + 4);
     uint64_t* d_fs = (uint64_t*)c->d_off;          // staging reuse: offsets buffer holds >= n + 1 u64
-    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_hash, n, c->d_keys, c->d_vals,
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const uint64_t*)c->d_hash, n, (const UniqSlot*)c->d_table,
                        c->uniq_mask, d_fs);
     CK_HIP(c, hipGetLastError());
     CK_HIP(c, hipMemcpyAsync(first_seen, d_fs, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -929,11 +979,11 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
 int circkit_uniq_insert_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t n, uint64_t base_index)
 {
     if (!c || (n && !d_hash)) return CIRCKIT_ERR_INVALID_ARG;
-    if (!c->d_keys) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
+    if (!c->d_table) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, (const uint64_t*)nullptr, n, base_index,
-                       c->d_keys, c->d_vals, c->uniq_mask, c->d_counters + 4);
+                       c->d_table, c->uniq_mask, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     c->uniq_count += n;
     return CIRCKIT_OK;
@@ -942,29 +992,38 @@ int circkit_uniq_insert_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
 int circkit_uniq_insert_pairs_device(circkit_ctx* c, const uint64_t* d_hash, const uint64_t* d_index, uint64_t n)
 {
     if (!c || (n && (!d_hash || !d_index))) return CIRCKIT_ERR_INVALID_ARG;
-    if (!c->d_keys) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
+    if (!c->d_table) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, d_index, n, (uint64_t)0, c->d_keys,
-                       c->d_vals, c->uniq_mask, c->d_counters + 4);
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, d_index, n, (uint64_t)0, c->d_table,
+                       c->uniq_mask, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     c->uniq_count += n;
     return CIRCKIT_OK;
 }
 
+// Enqueues the lookups; a table overflow of the inserts before it is reported by circkit_uniq_status (or by the next
+// synchronising uniq call) -- this call itself does not wait for the GPU.
 int circkit_uniq_lookup_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen)
 {
     if (!c || (n && (!d_hash || !d_first_seen))) return CIRCKIT_ERR_INVALID_ARG;
-    if (!c->d_keys) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
+    if (!c->d_table) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, c->d_keys, c->d_vals,
-                       c->uniq_mask, d_first_seen);
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen);
     CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_status(circkit_ctx* c, uint32_t* n_overflowed)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
     uint32_t overflow = 0;
     CK_HIP(c, hipMemcpyAsync(&overflow, c->d_counters + 4, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
-    if (overflow) return fail(c, CIRCKIT_ERR_OOM, "uniq table overflow: more distinct keys than circkit_uniq_reset sized it for");
+    if (n_overflowed) *n_overflowed = overflow;
+    if (overflow) return fail(c, CIRCKIT_ERR_OOM, "uniq table overflow: %u key(s) found no slot (more distinct keys than circkit_uniq_reset sized it for)", overflow);
     return CIRCKIT_OK;
 }
 
@@ -990,17 +1049,7 @@ int circkit_fixed_offsets_device(circkit_ctx* c, uint64_t base, uint64_t len, ui
 // needletail 0.5.1 sequence::normalize(seq, false) -- host logic of the CSR packer.
 size_t circkit_normalize(const uint8_t* s, size_t n, uint8_t* out, int* changed)
 {
-    static uint8_t lut[256];
-    static bool ready = false;
-    if (!ready) {
-        for (int v = 0; v < 256; ++v) lut[v] = 'N';
-        const char* keep = "ACGTN-";
-        for (int i = 0; keep[i]; ++i) lut[(uint8_t)keep[i]] = (uint8_t)keep[i];
-        lut['a'] = 'A'; lut['c'] = 'C'; lut['g'] = 'G'; lut['t'] = 'T'; lut['u'] = 'T'; lut['U'] = 'T';
-        lut['.'] = '-'; lut['~'] = '-';
-        lut[' '] = 0; lut['\t'] = 0; lut['\r'] = 0; lut['\n'] = 0;
-        ready = true;
-    }
+    const uint8_t* lut = ckhost::normalize_lut();     // fasta_host.cpp: one table, built once (thread-safe)
     size_t m = 0; int ch = 0;
     for (size_t i = 0; i < n; ++i) {
         const uint8_t c = s[i], o = lut[c];

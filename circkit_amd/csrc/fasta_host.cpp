@@ -28,20 +28,23 @@ void ByteBuf::reserve(size_t n)
 
 const uint8_t* normalize_lut()
 {
-    static uint8_t lut[256];
-    static bool ready = false;
-    if (!ready) {
-        // needletail 0.5.1 sequence::normalize(_, iupac = false): ACGTN- kept, acg -> upper, t/u/U -> T,
-        // . ~ -> -, whitespace dropped, everything else -> N
-        for (int v = 0; v < 256; ++v) lut[v] = 'N';
-        const char* keep = "ACGTN-";
-        for (int i = 0; keep[i]; ++i) lut[(uint8_t)keep[i]] = (uint8_t)keep[i];
-        lut['a'] = 'A'; lut['c'] = 'C'; lut['g'] = 'G'; lut['t'] = 'T'; lut['u'] = 'T'; lut['U'] = 'T';
-        lut['.'] = '-'; lut['~'] = '-';
-        lut[' '] = 0; lut['\t'] = 0; lut['\r'] = 0; lut['\n'] = 0;
-        ready = true;
-    }
-    return lut;
+    // needletail 0.5.1 sequence::normalize(_, iupac = false): ACGTN- kept, acg -> upper, t/u/U -> T,
+    // . ~ -> -, whitespace dropped, everything else -> N.  A function-local static with an initializer is built once,
+    // thread-safely (parser threads call this concurrently on their first chunk).
+    struct Table {
+        uint8_t v[256];
+        Table()
+        {
+            for (int i = 0; i < 256; ++i) v[i] = 'N';
+            const char* keep = "ACGTN-";
+            for (int i = 0; keep[i]; ++i) v[(uint8_t)keep[i]] = (uint8_t)keep[i];
+            v['a'] = 'A'; v['c'] = 'C'; v['g'] = 'G'; v['t'] = 'T'; v['u'] = 'T'; v['U'] = 'T';
+            v['.'] = '-'; v['~'] = '-';
+            v[' '] = 0; v['\t'] = 0; v['\r'] = 0; v['\n'] = 0;
+        }
+    };
+    static const Table table;
+    return table.v;
 }
 
 bool parse_chunk(const uint8_t* text, size_t n, bool first_chunk, bool final_chunk, Batch& out, size_t* consumed,

@@ -26,24 +26,41 @@ import torch.distributed as dist
 
 
 class DeviceTable:
-    """The circkit_ctx hash table (HIP kernels) behind the two calls the merge needs."""
+    """The circkit_ctx hash table (HIP kernels) behind the calls the merge needs.
+
+    Stream ordering: the table kernels read tensors that torch ops and RCCL collectives have just produced, so they
+    must run on the stream those are ordered on.  Every call therefore (re)binds the ctx to torch's CURRENT stream
+    of the ctx's device -- a blocking collective (`async_op=False`) makes that stream wait for RCCL's -- instead of
+    the ctx's private non-blocking stream, which is ordered after nothing."""
 
     def __init__(self, ctx):
         self.ctx = ctx
+        self._bind()
+
+    def _bind(self):
+        self.ctx.set_stream(torch.cuda.current_stream(self.ctx.device).cuda_stream)
 
     def reset(self, expected_keys):
+        self._bind()
         self.ctx.uniq_reset(expected_keys)
 
     def insert(self, hashes, base_index):
+        self._bind()
         self.ctx.uniq_insert_device(hashes, hashes.numel(), base_index)
 
     def insert_pairs(self, hashes, indices):
+        self._bind()
         self.ctx.uniq_insert_pairs_device(hashes, indices, hashes.numel())
 
     def lookup(self, hashes):
+        self._bind()
         out = torch.empty_like(hashes)
         self.ctx.uniq_lookup_device(hashes, hashes.numel(), out)
         return out
+
+    def check(self):
+        """Waits for the queued table work; raises if the table overflowed."""
+        self.ctx.uniq_status()
 
 
 def _owner(hashes, world):
@@ -51,14 +68,16 @@ def _owner(hashes, world):
     return ((hashes >> 20) & 0x7FFFFFFF) % world
 
 
-def first_seen(table, hashes, base_index=0, group=None, exchange="partition"):
+def first_seen(table, hashes, base_index=0, group=None, exchange="partition", force_exchange=False):
     """hashes: int64/uint64 tensor of this rank's shard (xxh3 of canonical records, input order);
     base_index: global index of this shard's record 0.  Returns (first_seen_global_index, keep_mask) for the
-    shard.  With an initialised process group duplicates are resolved across all ranks (see the module docstring)."""
+    shard.  With an initialised process group duplicates are resolved across all ranks (see the module docstring).
+    force_exchange: run the collectives even in a group of one rank (rehearses the RCCL path on a single GPU)."""
     n = hashes.numel()
-    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
     idx = torch.arange(base_index, base_index + n, dtype=torch.int64, device=hashes.device)
-    if world == 1:
+    if world == 1 and not (force_exchange and initialised):
         table.reset(n)
         table.insert(hashes, base_index)
         fs = table.lookup(hashes)

@@ -71,9 +71,12 @@ int circkit_ctx_last_kernel_ms(circkit_ctx* ctx, float* ms);
  *   d_out_xxh3   nullable; uint64[n_records]: XXH3-64 (seed 0) of the canonical sequence
  * n_records must be < 2^31 and every record shorter than 2^31 bytes.  No alignment or padding is required of
  * d_bytes / d_out_bytes, and offsets[0] need not be 0.
- * Records too long for the on-chip tiers (pure ACGT beyond ~260 kb, other alphabets beyond ~76-130 kb) are
- * finished in a global-memory scratch by circkit_ctx_synchronize() / circkit_ctx_batch_status(): call one of them
- * before consuming a batch that may hold such records, and before enqueuing the next batch on this ctx. */
+ * The call enqueues EVERYTHING the batch needs: once the stream has run past it the outputs are complete, whichever
+ * way the caller synchronises, and the next batch may be enqueued straight behind it.  Records too long for the
+ * on-chip tiers (pure ACGT beyond ~260 kb, other alphabets beyond ~76-130 kb) are taken by the batch's last two
+ * kernels in a ctx-owned global-memory scratch (256 MiB unless circkit_ctx_set_long_record_scratch says otherwise:
+ * pure ACGT up to ~430 Mb, arbitrary bytes up to ~126 MB); a record beyond that is left untouched and counted by
+ * circkit_ctx_batch_status. */
 int circkit_canonicalize_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                                       uint64_t n_records, uint8_t* d_out_bytes, uint32_t* d_out_index,
                                       uint8_t* d_out_strand, uint64_t* d_out_xxh3);
@@ -86,10 +89,19 @@ int circkit_lmsr_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const ui
 int circkit_xxh3_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                               uint64_t n_records, uint64_t* d_out_xxh3);
 
-/* Completes the most recent batch (synchronizes; runs the long-record pass if that batch needs it) and returns
- * the number of its records that could not be processed at all (2^31 symbols or more; they were left untouched):
- * non-zero makes the status CIRCKIT_ERR_TOO_LONG. */
+/* Waits for the most recent batch and returns the number of its records that could not be processed (longer than
+ * the long-record scratch allows, or 2^31 symbols or more; they were left untouched): non-zero makes the status
+ * CIRCKIT_ERR_TOO_LONG. */
 int circkit_ctx_batch_status(circkit_ctx* ctx, uint32_t* n_unprocessed);
+/* Size in bytes of the global-memory scratch the device entry points give to records beyond the on-chip tiers (a
+ * record of n symbols needs ~0.63 n bytes when pure ACGT, ~1.13 n for {-,A,C,G,N,T}, ~2.13 n otherwise).  The
+ * host-buffer entry points see the lengths and grow the scratch by themselves.  Synchronizes. */
+int circkit_ctx_set_long_record_scratch(circkit_ctx* ctx, uint64_t bytes);
+/* Which build of the streaming kernel the most recent device batch selected, from that batch's own lengths: 1 = one
+ * packed word per lane (records up to 1008 b), 2 = two words (a quarter or more of the records in 1009..2032 b),
+ * 3 = neither (an eighth or more of the records longer; the per-record passes take everything).  Diagnostic: every
+ * mode computes the same results.  Synchronizes. */
+int circkit_ctx_last_batch_mode(circkit_ctx* ctx, uint32_t* mode);
 
 /* ---- batch, host buffers ---------------------------------------------------------------------- */
 /* Same contract with HOST pointers: copies the batch into ctx-owned device buffers (grow-only), runs
@@ -131,6 +143,9 @@ int circkit_uniq_insert_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_
  * partition, circkit_amd/uniq.py) are a subset of every other rank's shard, not a contiguous range */
 int circkit_uniq_insert_pairs_device(circkit_ctx* ctx, const uint64_t* d_hash, const uint64_t* d_index, uint64_t n);
 int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen);
+/* reset / insert / lookup only enqueue work.  circkit_uniq_status waits for it and fails with CIRCKIT_ERR_OOM when
+ * keys found no slot (more distinct keys than circkit_uniq_reset was told to expect); *n_overflowed (nullable) = how many. */
+int circkit_uniq_status(circkit_ctx* ctx, uint32_t* n_overflowed);
 
 /* Host-buffer form for streaming hosts (the CLI's batch loop): folds this batch's hashes (global indices
  * base_index .. base_index + n - 1) into the ctx table -- created and grown on demand, earlier batches kept --

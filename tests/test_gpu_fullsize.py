@@ -1,0 +1,175 @@
+"""GPU tests at BASELINE.json's full sizes (configs 3 and 4), of the per-batch build selection, and of the multi-GPU
+`uniq` exchange over RCCL (backend nccl, rehearsed at world size 1 on the box's one GPU).  Run on a real MI355X:
+pytest -m gpu.  Full-size checks use the size-independent properties of the canonical form (idempotence, rotation and
+strand invariance, the expected number of distinct records) plus the oracle on a slice, as SURVEY.md 8(d) prescribes."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    import circkit_amd
+    c = circkit_amd.Context(0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    yield c
+    c.close()
+
+
+def test_uniq_config3_full_size(ctx, O):
+    """BASELINE configs[2] as bench.py generates it: 10M x 1 kb, half of the records rotated / reverse-complemented
+    copies of the other half, shuffled.  Exactly 5,000,000 records survive; first-seen indices of the first 100k
+    records equal the oracle's on the oracle's own hashes of that sample (SURVEY.md 8d cfg 3)."""
+    import torch
+    from circkit_amd import uniq, workloads as W
+    N, L = 10_000_000, 1000
+    dev = torch.device("cuda", 0)
+    x, off = W.fixed_length(ctx, dev, N, L, 42, 0)
+    W.plant_duplicates(x, N, L, dev, 43, 44)
+    out = torch.empty_like(x)
+    hs = torch.empty(N, dtype=torch.int64, device=dev)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=out, out_xxh3=hs)
+    assert ctx.batch_status() == 0
+    table = uniq.DeviceTable(ctx)
+    fs, keep = uniq.first_seen(table, hs, base_index=0)
+    table.check()
+    assert int(keep.sum().item()) == N - N // 2
+    # a record is kept iff nothing before it has its hash, and every record points at a kept one with the same hash
+    assert bool((fs <= torch.arange(N, device=dev)).all())
+    assert bool(keep[fs].all()) and bool((hs[fs] == hs).all())
+    S = 100_000
+    h_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(L)
+    exp, exp_h = O.canonicalize_batch(x[:S * L].cpu().numpy(), h_off, True, True, threads=8)
+    assert np.array_equal(out[:S * L].cpu().numpy(), exp)
+    assert np.array_equal(hs[:S].cpu().numpy().astype(np.uint64), exp_h)
+    assert np.array_equal(fs[:S].cpu().numpy().astype(np.uint64), O.uniq_first_seen(exp_h))
+    # hash-only mode (uniq without --canonicalize) gives the same hashes without an output buffer
+    hs2 = torch.empty_like(hs)
+    ctx.canonicalize_batch_device(x, off, N, out_xxh3=hs2)
+    torch.cuda.synchronize()
+    assert torch.equal(hs, hs2)
+
+
+@pytest.mark.parametrize("n_frac", [0.0, 0.01])
+def test_mixed_config4_full_size(ctx, O, n_frac):
+    """BASELINE configs[3] at its full 1M records (4.3 Gbases, lengths log-uniform on [200, 20000]), and its 1 % N
+    variant: oracle bytes on a 5k-record slice; over all records idempotence and invariance under reverse
+    complement + rotation."""
+    import torch
+    from circkit_amd import workloads as W
+    N = 1_000_000
+    dev = torch.device("cuda", 0)
+    offs = W.log_uniform_offsets(N, 45)
+    total = int(offs[-1])
+    off = offs.to(dev)
+    x = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    ctx.synth_fill_device(45, 0, total, x)
+    if n_frac:
+        W.sprinkle_n(x, total, n_frac, 46, dev)
+    c1 = torch.full_like(x, 0x3F)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=c1)
+    assert ctx.batch_status() == 0
+    assert ctx.last_batch_mode() == 3                       # a third of the records are longer than 2032 bases
+    assert bool((c1[total:] == 0x3F).all())
+    S = 5000
+    h_off = offs[:S + 1].numpy().astype(np.uint64)
+    nb = int(h_off[-1])
+    exp, _ = O.canonicalize_batch(x[:nb].cpu().numpy(), h_off, True, False, threads=8)
+    assert np.array_equal(c1[:nb].cpu().numpy(), exp)
+    c2 = torch.empty_like(x)
+    ctx.canonicalize_batch_device(c1, off, N, out_bytes=c2)
+    torch.cuda.synchronize()
+    assert torch.equal(c1[:total], c2[:total]), "not idempotent"
+    del c2
+    y = W.revcomp_rotate_csr(x, off, N, dev, shift=137)
+    c3 = torch.empty_like(x)
+    ctx.canonicalize_batch_device(y, off, N, out_bytes=c3)
+    torch.cuda.synchronize()
+    assert torch.equal(c1[:total], c3[:total]), "canonical form changed under reverse complement + rotation"
+
+
+def test_one_percent_n_headline_shape(ctx, O):
+    """10M x 1 kb with 1 % N (practically every record holds an N): oracle on a slice, idempotence over everything."""
+    import torch
+    from circkit_amd import workloads as W
+    N, L = 10_000_000, 1000
+    dev = torch.device("cuda", 0)
+    x, off = W.fixed_length(ctx, dev, N, L, 42, 0)
+    W.sprinkle_n(x, N * L, 0.01, 46, dev)
+    c1 = torch.empty_like(x)
+    hs = torch.empty(N, dtype=torch.int64, device=dev)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=c1, out_xxh3=hs)
+    assert ctx.batch_status() == 0
+    S = 20000
+    exp, exp_h = O.canonicalize_batch(x[:S * L].cpu().numpy(), np.arange(S + 1, dtype=np.uint64) * np.uint64(L), True, True, 8)
+    assert np.array_equal(c1[:S * L].cpu().numpy(), exp)
+    assert np.array_equal(hs[:S].cpu().numpy().astype(np.uint64), exp_h)
+    c2 = torch.empty_like(x)
+    ctx.canonicalize_batch_device(c1, off, N, out_bytes=c2)
+    torch.cuda.synchronize()
+    assert torch.equal(c1[:N * L], c2[:N * L])
+
+
+def test_build_selection_follows_the_batch_not_the_buffer(ctx, O):
+    """A streaming host reuses ONE offsets buffer: a batch of short records, then a batch of 1.5 kb records, then
+    short ones again.  The mode is decided from each batch's own lengths (1, 2, 1), never remembered by pointer."""
+    import torch
+    from tests import seqsets
+    dev = torch.device("cuda", 0)
+    n = 4000
+    batches = [seqsets.random_mixed(201, n, 300, 1008), seqsets.random_mixed(202, n, 1400, 1600), seqsets.random_mixed(203, n, 48, 900)]
+    cap = max(sum(len(s) for s in b) for b in batches)
+    d_bytes = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+    d_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)          # the one offsets buffer
+    d_out = torch.zeros_like(d_bytes)
+    for seqs, want_mode in zip(batches, (1, 2, 1)):
+        data, offs = seqsets.pack(seqs)
+        d_bytes[:len(data)] = torch.from_numpy(data).to(dev)
+        d_off.copy_(torch.from_numpy(offs.astype(np.int64)))
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out)
+        assert ctx.last_batch_mode() == want_mode
+        exp, _ = O.canonicalize_batch(data, offs, True, False, threads=8)
+        assert np.array_equal(d_out[:len(data)].cpu().numpy(), exp)
+
+
+def _run(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("exchange", ["partition", "allgather"])
+def test_uniq_exchange_over_rccl_world_1(exchange):
+    """circkit_amd/uniq.py's multi-GPU path with the HIP table on a device and backend nccl (= RCCL): all_to_all_single
+    / all_gather + circkit_uniq_insert_pairs_device + lookup, checked against the oracle's first-seen.  One rank (the
+    box has one GPU); its own process because it owns a process group."""
+    out = _run([sys.executable, os.path.join(ROOT, "tools", "gpu_uniq_nccl.py"), exchange])
+    assert "first-seen matches the oracle" in out
+
+
+def test_bench_uniq_runs_the_exchange_and_counts_globally():
+    """bench.py --workload uniq with the RCCL path forced: the timed step calls uniq.first_seen over nccl and the line
+    reports the job's unique count (bench.py itself fails if it is not records/2)."""
+    import json
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "uniq", "--records", "400000", "--steps", "2", "--warmup", "1"],
+               env={"CIRCKIT_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29541"})
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["unique_records"] == 200000
+    assert "RCCL" in line["config"]["parallelism"]
+    assert line["cpu_baseline"]["gpu_output_matches"] is True

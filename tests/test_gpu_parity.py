@@ -140,7 +140,8 @@ def test_lds_tiers_long_records(ctx, O):
 
 def test_records_beyond_the_lds_tiers(ctx, O):
     """Records no LDS tier can hold (2-bit beyond ~260 kb, with N beyond ~130 kb, arbitrary bytes beyond ~76 kb) are
-    finished in global scratch by the same code: host API, all outputs; mixed into a batch of ordinary records."""
+    taken by the batch's last two kernels in global scratch, same code: host API, all outputs; mixed into a batch of
+    ordinary records."""
     from tests import seqsets
     rng = np.random.default_rng(3)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -154,9 +155,9 @@ def test_records_beyond_the_lds_tiers(ctx, O):
     _check(ctx, O, seqs)
 
 
-def test_device_api_finishes_long_records_at_synchronize(ctx, O):
-    """Device API: the batch call stays asynchronous; records beyond the LDS tiers are completed by
-    circkit_ctx_synchronize() / circkit_ctx_batch_status()."""
+def test_device_api_finishes_long_records_on_the_device(ctx, O):
+    """Device API: the batch call enqueues everything, records beyond the LDS tiers included (global-scratch stages);
+    any synchronisation with the stream is enough."""
     import torch
     from tests import seqsets
     rng = np.random.default_rng(4)
@@ -171,16 +172,75 @@ def test_device_api_finishes_long_records_at_synchronize(ctx, O):
     d_out = torch.zeros_like(d_bytes)
     d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
     ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash)
-    assert ctx.batch_status() == 0
+    torch.cuda.synchronize()                         # the caller's own synchronisation, not the library's
     exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
     assert np.array_equal(d_out.cpu().numpy(), exp)
     assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    assert ctx.batch_status() == 0
     # hash-only batch (uniq without --canonicalize): canonical bytes live in the ctx's scratch
     d_hash.zero_()
     ctx.canonicalize_batch_device(d_bytes, d_off, n, out_xxh3=d_hash)
     ctx.synchronize()
     assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
     ctx.use_own_stream()
+
+
+def test_back_to_back_device_batches_with_long_records(ctx, O):
+    """Two device batches enqueued one behind the other with NO synchronisation in between, the first holding records
+    beyond the LDS tiers: both complete (an earlier design finished such records from the host at the next
+    synchronisation point and lost them when a second batch was enqueued first)."""
+    import torch
+    from tests import seqsets
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    first = seqsets.random_mixed(85, 40, 500, 1008) + [acgt[rng.integers(0, 4, 400_000)].tobytes(),
+                                                       np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 150_000)].tobytes()]
+    second = seqsets.random_mixed(86, 300, 48, 1008)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    bufs = []
+    for seqs in (first, second):
+        data, offs = seqsets.pack(seqs)
+        d_bytes = torch.from_numpy(data).to(dev)
+        bufs.append((data, offs, len(seqs), d_bytes, torch.from_numpy(offs.astype(np.int64)).to(dev), torch.zeros_like(d_bytes),
+                     torch.zeros(len(seqs), dtype=torch.int64, device=dev)))
+    torch.cuda.synchronize()
+    for _, _, n, d_bytes, d_off, d_out, d_hash in bufs:
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash)
+    torch.cuda.synchronize()
+    for data, offs, n, _, _, d_out, d_hash in bufs:
+        exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+        assert np.array_equal(d_out.cpu().numpy(), exp)
+        assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    assert ctx.batch_status() == 0
+    ctx.use_own_stream()
+
+
+def test_long_record_scratch_limit_is_reported(O):
+    """A record beyond the long-record scratch is left untouched and counted by circkit_ctx_batch_status (device API;
+    the host API sizes the scratch itself)."""
+    import torch
+    import circkit_amd
+    from tests import seqsets
+    c = circkit_amd.Context(0)
+    c.set_long_record_scratch(1 << 20)               # 1 MiB: pure-ACGT records up to ~1.6 Mb
+    rng = np.random.default_rng(6)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = seqsets.random_mixed(87, 20, 100, 1008) + [acgt[rng.integers(0, 4, 1_000_000)].tobytes(), acgt[rng.integers(0, 4, 2_500_000)].tobytes()]
+    data, offs = seqsets.pack(seqs)
+    dev = torch.device("cuda", 0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_out = torch.zeros_like(d_bytes)
+    c.canonicalize_batch_device(d_bytes, d_off, len(seqs), out_bytes=d_out)
+    assert c.batch_status() == 1
+    exp, _ = O.canonicalize_batch(data, offs, True, False, threads=8)
+    cut = int(offs[-2])
+    assert np.array_equal(d_out.cpu().numpy()[:cut], exp[:cut])           # everything but the refused record
+    got = c.canonicalize_batch(data, offs)                                # host API: grows the scratch
+    assert np.array_equal(got["bytes"], exp)
+    c.close()
 
 
 def test_zipf_mixed_lengths_config4_shape(ctx, O):
@@ -231,8 +291,24 @@ def test_full_size_properties_10m_x_1kb(ctx, O):
     assert ctx.batch_status() == 0
     # oracle parity on a slice
     S = 20000
-    exp, _ = O.canonicalize_batch(x[:S * L].cpu().numpy(), np.arange(S + 1, dtype=np.uint64) * np.uint64(L), True, False, 8)
+    exp, exp_h = O.canonicalize_batch(x[:S * L].cpu().numpy(), np.arange(S + 1, dtype=np.uint64) * np.uint64(L), True, True, 8)
     assert np.array_equal(c1[:S * L].cpu().numpy(), exp)
+    # the benchmarked build -- canonical bytes only: canon_stream_kernel<StreamCfg<16,2,1,1>,false,false> -- over all
+    # 10M records against the build with every output, and with it against the oracle slice
+    c0 = torch.full_like(x, 0x3F)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=c0)
+    assert ctx.batch_status() == 0
+    assert ctx.last_batch_mode() == 1
+    assert torch.equal(c0[:N * L], c1[:N * L])
+    assert bool((c0[N * L:] == 0x3F).all())
+    # ...and the uniq build (bytes + fused XXH3): same bytes, hashes = oracle's on the slice
+    hs = torch.empty(N, dtype=torch.int64, device=dev)
+    c0.fill_(0x3F)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=c0, out_xxh3=hs)
+    torch.cuda.synchronize()
+    assert torch.equal(c0[:N * L], c1[:N * L])
+    assert np.array_equal(hs[:S].cpu().numpy().astype(np.uint64), exp_h)
+    del c0, hs
     # idempotence: canonical input -> identical output, rotation index 0 whenever the forward strand is returned
     c2 = torch.empty_like(x)
     s2 = torch.empty_like(strand)
@@ -480,9 +556,9 @@ def test_uniq_insert_pairs_device(ctx, O):
 
 
 def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
-    """The ROWS == 2 build of the streaming kernel (records up to 2032 bases, two packed words per lane): chosen by the
-    batch's mean length -- by the host for host buffers, on the device for device buffers (first call: both builds are
-    launched; later calls with the same offsets array: the remembered one)."""
+    """The ROWS == 2 build of the streaming kernel (records up to 2032 bases, two packed words per lane): chosen from the
+    batch's lengths -- by the host for host buffers, on the device for device buffers (both builds are launched, the
+    one the previous batch used with the full-size grid)."""
     import torch
     from tests import seqsets
     seqs = seqsets.random_mixed(101, 600, 1009, 2032) + seqsets.random_mixed(102, 60, 1009, 2032, b"ACGTN") + \
@@ -497,10 +573,11 @@ def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
     d_bytes = torch.from_numpy(data).to(dev)
     d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
     d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
-    for rep in range(3):                                            # 1st: device decides; 2nd / 3rd: remembered
+    for rep in range(3):                                            # 1st: small-grid fallback runs it; 2nd / 3rd: full grid
         d_out = torch.zeros_like(d_bytes)
         ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep else None)
         torch.cuda.synchronize()
+        assert ctx.last_batch_mode() == 2
         assert np.array_equal(d_out.cpu().numpy(), exp), rep
         if rep:
             assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
@@ -520,7 +597,7 @@ def test_randomized_rare_paths_long_profile():
 
 def test_device_api_batch_full_of_long_records(ctx, O):
     """Mode 3 of launch_canon decided on the device: with one record in eight beyond 2032 bases the staged kernel is
-    skipped and the rescue pass walks every record (first call: decided by the counting kernel; later: remembered)."""
+    skipped and the rescue pass walks every record."""
     import torch
     from tests import seqsets
     seqs = seqsets.random_mixed(111, 400, 48, 1008) + seqsets.random_mixed(112, 150, 2500, 9000) + \
@@ -541,6 +618,7 @@ def test_device_api_batch_full_of_long_records(ctx, O):
         ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep else None,
                                       out_index=d_idx if rep == 2 else None)
         torch.cuda.synchronize()
+        assert ctx.last_batch_mode() == 3
         assert np.array_equal(d_out.cpu().numpy(), exp), rep
         if rep:
             assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
