@@ -109,6 +109,81 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
     return ((uint64_t)readlane((uint32_t)(h >> 32), 15) << 32) | readlane((uint32_t)h, 15);
 }
 
+// ---- XXH3-64 merged per record GROUP (the 16-wave streaming build) -----------------------------------------------
+// fast_hash() above spends most of its instructions on work that is the same for every record and uses 4 lanes of
+// 64: the cross-row butterfly (8 ds_bpermute), the last stripe (2 ds_bpermute + a 16-byte decode), the 64x64->128
+// merge fold and the avalanche (~18 quarter-rate multiplies).  In the 16-wave build every wave therefore only
+// leaves its per-row partial sums (lanes 12..15 of each 16-lane row), its packed winning strand and (n, idx) in an
+// LDS slot; after the iteration's barrier ONE wave (a different one each iteration) finishes all 16 records at once,
+// lane t = (record t>>2, accumulator pair t&3), and stores 16 hashes with one instruction.  Slots are double-buffered
+// by iteration parity: the merger reads group g while the others fill the slots of group g+1.
+//   slot (GH_STRIDE_DW dwords): [0,64) partial sums: entry (row, pair) = {c0, c1}; [64,128) packed words of the
+//   winning strand (extension included); [128..130] n, idx, valid.  576 B apart: the merger's 16-byte reads of one
+//   entry from 16 slots are bank-conflict-free.
+constexpr uint32_t GH_STRIDE_DW = 144;
+constexpr uint32_t GH_CONST_DW = 48;            // per accumulator pair j: l0 l1 m0 m1 i0 i1 (6 x u64)
+template <int GROUP>
+constexpr uint32_t gh_lds_dw() { return 2 * GROUP * GH_STRIDE_DW + GH_CONST_DW; }
+CK_DEV void group_hash_init(uint32_t* ghc, uint32_t tid)
+{
+    if (tid < 4) {
+        const uint32_t j = tid;
+        const uint64_t v[6] = { xsec64(121 + 16 * j), xsec64(129 + 16 * j), xsec64(11 + 16 * j), xsec64(19 + 16 * j),
+                                j == 0 ? XP32_3 : j == 1 ? XP64_2 : j == 2 ? XP64_4 : XP64_5,
+                                j == 0 ? XP64_1 : j == 1 ? XP64_3 : j == 2 ? XP32_2 : XP32_1 };
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { ghc[12 * j + 2 * k] = (uint32_t)v[k]; ghc[12 * j + 2 * k + 1] = (uint32_t)(v[k] >> 32); }
+    }
+}
+CK_DEV void group_hash_invalidate(uint32_t* slot) { if (lane_id() == 0) slot[130] = 0; }
+// producer: `cell` = this lane's 16 canonical bytes [16t, 16t+16); k0 / k1 = secret words of the lane's cell
+CK_DEV void group_hash_put(uint32_t* slot, uint64_t k0, uint64_t k1, u32x4 cell, uint32_t E, uint32_t idx, uint32_t n)
+{
+    const uint32_t t = lane_id();
+    const uint32_t stripes = (n - 1) >> 6;                       // full 64-byte stripes before the last one
+    const uint64_t d0 = ((uint64_t)cell.y << 32) | cell.x, d1 = ((uint64_t)cell.w << 32) | cell.z;
+    const uint64_t x0 = d0 ^ k0, x1 = d1 ^ k1;
+    const bool on = t < 4 * stripes;
+    uint64_t c0 = on ? d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32) : 0;
+    uint64_t c1 = on ? d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32) : 0;
+    dpp_rowsum4_u64x2(c0, c1);                                   // lanes 12..15 of each row: row sums of pair t&3
+    if ((t & 15) >= 12) lds_store16(slot + (t >> 4) * 16 + (t & 3) * 4, u32x4{ (uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32) });
+    slot[64 + t] = E;
+    if (t == 0) { slot[128] = n; slot[129] = idx; slot[130] = 1; }
+}
+// merger: finishes the GROUP records of `slots` (records rec0 .. rec0 + GROUP - 1 of the batch)
+template <int GROUP>
+CK_DEV void group_hash_merge(const CanonArgs& a, const uint32_t* lut, const uint32_t* ghc, const uint32_t* slots, uint32_t rec0)
+{
+    static_assert(GROUP == 16, "one lane per (record, accumulator pair)");
+    const uint32_t t = lane_id(), r = t >> 2, j = t & 3;
+    const uint32_t* s = slots + r * GH_STRIDE_DW;
+    const bool valid = s[130] != 0;
+    const uint32_t n = valid ? s[128] : 64u, idx = valid ? s[129] : 0u;       // (a dummy that keeps the reads inside the slot)
+    const u32x4 cl = lds_load16(ghc + 12 * j), cm = lds_load16(ghc + 12 * j + 4), ci = lds_load16(ghc + 12 * j + 8);
+    uint64_t a0 = ((uint64_t)ci.y << 32) | ci.x, a1 = ((uint64_t)ci.w << 32) | ci.z;
+#pragma unroll
+    for (uint32_t row = 0; row < 4; ++row) {
+        const u32x4 v = lds_load16(s + row * 16 + j * 4);
+        a0 += ((uint64_t)v.y << 32) | v.x;
+        a1 += ((uint64_t)v.w << 32) | v.z;
+    }
+    {   // last stripe: the final 64 bytes, pair j = bytes [n-64+16j, n-48+16j)
+        uint32_t p = idx + (n - 64) + 16 * j;
+        p = p >= n ? p - n : p;
+        const uint32_t wi = p >> 4;
+        const u32x4 b = fast_decode(lut, lshr64(s[64 + wi], s[64 + wi + 1], 32 - (p & 15) * 2));
+        const uint64_t d0 = ((uint64_t)b.y << 32) | b.x, d1 = ((uint64_t)b.w << 32) | b.z;
+        const uint64_t x0 = d0 ^ (((uint64_t)cl.y << 32) | cl.x), x1 = d1 ^ (((uint64_t)cl.w << 32) | cl.z);
+        a0 += d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32);
+        a1 += d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32);
+    }
+    uint64_t q = xfold(a0 ^ (((uint64_t)cm.y << 32) | cm.x), a1 ^ (((uint64_t)cm.w << 32) | cm.z));
+    q = dpp_quadsum_u64(q);                                                   // sum over the four pairs of the record
+    const uint64_t h = xaval3((uint64_t)n * XP64_1 + q);
+    if (valid && j == 0) { a.out_hash[rec0 + r] = h; a.hashed[rec0 + r] = 1; }
+}
+
 // Canonicalizes one eligible record held as packed words: lane t = symbols [16t, 16t+16) (whatever follows the
 // record in the tail word is replaced by the periodic extension), bad = wave mask of lanes holding a byte outside
 // ACGT.  Returns false (nothing written) when the record must go to the general kernel: an invalid byte, a minimal
@@ -140,9 +215,10 @@ CK_DEV void fast_shape(FastShape& sh, uint32_t n)
 
 // HASH = false compiles the fused XXH3 out; AUX = false compiles out what only some callers ask for (rotation index
 // and strand outputs, forward-only mode).
+// gh_slot != nullptr: the hash is finished by the workgroup's merger (group_hash_put), else here (fast_hash).
 template <bool HASH, bool AUX>
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
-                       uint32_t n, uint32_t F, uint64_t bad)
+                       uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr)
 {
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
@@ -191,8 +267,12 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
             const u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
             if (store && valid) store16(a.out_bytes + off + o, cell);
             if (hash) {
-                const uint64_t h = fast_hash(hc, lut, cell, E, idx, n);
-                if (t == 0) { a.out_hash[rec] = h; a.hashed[rec] = 1; }
+                if (gh_slot) {
+                    group_hash_put(gh_slot, hc.k0, hc.k1, cell, E, idx, n);
+                } else {
+                    const uint64_t h = fast_hash(hc, lut, cell, E, idx, n);
+                    if (t == 0) { a.out_hash[rec] = h; a.hashed[rec] = 1; }
+                }
             }
         }
     }

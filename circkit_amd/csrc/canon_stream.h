@@ -80,12 +80,15 @@ CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, u
     return grp;
 }
 
-// loop of one wave of a workgroup; every wave of the workgroup runs the same number of iterations (barriers inside)
-template <class C, bool HASH, bool AUX>
+// loop of one wave of a workgroup; every wave of the workgroup runs the same number of iterations (barriers inside).
+// GH: XXH3 is finished per record group by one wave (canon_fast.h, group_hash_*); gh = its LDS area (gh_lds_dw<GROUP>()
+// dwords, constants initialised by group_hash_init).
+template <class C, bool HASH, bool AUX, bool GH = false>
 CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* ring, uint32_t* blk_count, uint32_t block,
-                                   uint32_t nblocks)
+                                   uint32_t nblocks, uint32_t* gh = nullptr)
 {
     static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
+    static_assert(!GH || (HASH && C::RPW == 1 && C::GROUP == 16), "the group merger takes 16 records, one per wave");
     constexpr int D = C::NBUF - 1;                    // groups in flight
     const uint32_t N = (uint32_t)a.n_records, n_groups = (N + C::GROUP - 1) / C::GROUP;
     if (N == 0) return;
@@ -99,7 +102,10 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     FastHashConst hc{};
     if (HASH) hc = fast_hash_const();
     FastShape shape;
-    const bool stores = a.out_bytes || a.out_hash || a.out_index || a.out_strand;     // else only deferrals store
+    // does every record issue at least one store (bytes, hash, index or its deferral)?  The vmcnt arithmetic below counts
+    // on it.  Not with the group merger on a hash-only batch: a record then leaves nothing but LDS writes.
+    const bool stores = GH ? (a.out_bytes && !(a.flags & CK_FLAG_BYTES_OPTIONAL)) : (a.out_bytes || a.out_hash || a.out_index || a.out_strand);
+    const uint32_t* gh_const = GH ? gh + 2 * C::GROUP * GH_STRIDE_DW : nullptr;
     uint32_t c16[C::DPW];
 #pragma unroll
     for (int i = 0; i < C::DPW; ++i) c16[i] = (stream_slot<C>(w, (uint32_t)i) * 64 + t) * 16;
@@ -124,6 +130,8 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         const uint32_t bf = bi ? bi - 1 : C::NBUF - 1;                     // the buffer freed by the previous iteration
         const StreamGroup fut = stream_issue<C>(a, gf < n_staged, s, e, ring + bf * C::BUF_DW, c16);
         const uint32_t* img = ring + bi * C::BUF_DW;
+        uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + w) * GH_STRIDE_DW : nullptr;
+        if (GH) group_hash_invalidate(slot);
 #pragma unroll
         for (int k = 0; k < C::RPW; ++k) {
             const uint64_t off = k ? o1 : o0;                           // (o2 is loaded but unused when RPW == 1)
@@ -149,9 +157,14 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
                 const uint64_t bad = ballot(miss != 0) & (~0ull >> (64 - nch));         // 3 <= nch <= 64
-                done = fast_canon<HASH, AUX>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad);
+                done = fast_canon<HASH, AUX>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
             }
             if (!done) defer_record(a, blk_count, block, rec);
+        }
+        // the previous group's hashes: its slots were complete at the barrier that ended the previous iteration
+        if constexpr (GH) {
+            if (it > 0 && w == ((it - 1) & (C::WPB - 1)))
+                group_hash_merge<(int)C::GROUP>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, (g - nblocks) * C::GROUP);
         }
         // the next group's DMAs (issued D-1 iterations ago) must have landed.  Younger vector-memory instructions:
         // the DMAs of the D-1 groups issued since (DPW each), and the stores of this and the D-1 previous iterations
@@ -165,6 +178,12 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         for (int d = 0; d + 1 < D; ++d) q[d] = q[d + 1];
         q[D - 1] = fut;
         bi = bi + 1 == (uint32_t)C::NBUF ? 0 : bi + 1;
+    }
+    if constexpr (GH) {
+        if (it > 0 && w == ((it - 1) & (C::WPB - 1))) {             // the last group's hashes (behind the loop's final barrier)
+            const uint32_t g_last = block + (it - 1) * nblocks;
+            group_hash_merge<(int)C::GROUP>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, g_last * C::GROUP);
+        }
     }
 }
 

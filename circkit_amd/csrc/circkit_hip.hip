@@ -60,6 +60,8 @@ __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, uint3
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
     ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && a.defer_count) a.defer_count[blockIdx.x] = blk_count;      // the next stage reads every segment's count
 }
 
 // XXH3-64 of the listed records (the ones canon_global_kernel finished after the batch's own hash pass)
@@ -149,19 +151,27 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 // `nvb` virtual workgroups (one list segment each) are walked by the launched ones: the build the host expects to
 // match the batch is launched with one workgroup per virtual one, the other build with a small grid -- its
 // workgroups normally return at once, and take the whole batch when the expectation was wrong.
+// GH: the fused XXH3 is finished per 16-record group by one wave (canon_fast.h group_hash_*): 18.2 KiB more LDS, which
+// the ROWS = 2 build cannot afford next to its 64 KiB of images (two workgroups per CU are what matters most).
+#ifndef CK_GROUP_HASH
+#define CK_GROUP_HASH 1
+#endif
 template <class StreamC, bool HASH, bool AUX>
 __global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ counts,
                                                                                                              uint32_t host_mode, uint32_t nvb)
 {
     if (batch_mode(counts, host_mode, a.n_records) != (uint32_t)StreamC::ROWS) return;    // the other build (or none) has this batch
-    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW];
+    constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && StreamC::RPW == 1 && StreamC::GROUP == 16;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<16>() : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + 256;
+    uint32_t* gh = lds + StreamC::LDS_DW;
     ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
+    if (GH) ck::group_hash_init(gh + 2 * 16 * ck::GH_STRIDE_DW, threadIdx.x);
     for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
-        ck::canon_stream_wave_loop<StreamC, HASH, AUX>(a, lut, lds, blk_count, vb, nvb);
+        ck::canon_stream_wave_loop<StreamC, HASH, AUX, GH>(a, lut, lds, blk_count, vb, nvb, gh);
         ck::vmem_wait<0>();                              // no DMA of this virtual workgroup may land in the next one's images
         __syncthreads();
         if (threadIdx.x == 0) a.defer_count[vb] = *blk_count;

@@ -281,6 +281,13 @@ CK_DEV u32x4 lds_load16(const uint32_t* p)
     return u32x4{ v.x, v.y, v.z, v.w };
 }
 
+CK_DEV void lds_store16(uint32_t* p, u32x4 v)      // 16-byte-aligned LDS address: one ds_write_b128
+{
+    typedef uint32_t v4 __attribute__((ext_vector_type(4), aligned(16)));
+    v4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *reinterpret_cast<v4*>(p) = t;
+}
+
 // two independent u64 (e.g. the first and last offset of a record group), one wait
 CK_DEV void sload_2u64(const uint64_t* p0, const uint64_t* p1, uint64_t& a, uint64_t& b)
 {
@@ -441,6 +448,7 @@ CK_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
     return c;
 }
 CK_DEV u32x4 lds_load16(const uint32_t* p) { u32x4 v; memcpy(&v, p, 16); return v; }
+CK_DEV void lds_store16(uint32_t* p, u32x4 v) { memcpy(p, &v, 16); }
 
 }  // namespace ck
 #endif

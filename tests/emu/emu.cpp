@@ -141,7 +141,11 @@ void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
     // same choice of build as launch_canon()
     const bool aux = L->a.out_index || L->a.out_strand || (L->a.flags & ck::CK_FLAG_FWD_ONLY);
     if (aux) ck::canon_stream_wave_loop<C, true, true>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
-    else if (L->a.out_hash) ck::canon_stream_wave_loop<C, true, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
+    else if (L->a.out_hash) {
+        // the 16-wave, one-word build finishes XXH3 per record group (same condition as canon_stream_kernel)
+        constexpr bool GH = C::ROWS == 1 && C::RPW == 1 && C::GROUP == 16;
+        ck::canon_stream_wave_loop<C, true, false, GH>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
+    }
     else ck::canon_stream_wave_loop<C, false, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
 }
 // geometries the staged streaming kernel is exercised with (index = `staged` argument - 1)
@@ -184,7 +188,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     const bool all_records = staged == 0;
     const uint64_t per_step = sv->group, steps = (n_records + per_step - 1) / per_step;
     const uint32_t cap = (uint32_t)(per_step * ((steps + G - 1) / G)) + 4;
-    std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16 + ck::gh_lds_dw<16>()), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    for (uint32_t tid = 0; tid < 4; ++tid) ck::group_hash_init(lds.data() + sv->lds_dw + 2 * 16 * ck::GH_STRIDE_DW, tid);
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[256];
     ck::fast_lut_init(lut, 0, 1);
