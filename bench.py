@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--length", type=int, default=1000)
     ap.add_argument("--n-frac", type=float, default=0.0, help="fraction of bases replaced by N (SURVEY 8d: the 1 %% N variants)")
     ap.add_argument("--cpu-sample", type=int, default=None,
-                    help="records timed on the host cores (rank 0, N=1); default: ~20k records per core")
+                    help="records timed on the host cores (rank 0, N=1); default: 100k records per usable core (~0.7 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--exchange", default="partition", choices=["partition", "allgather"], help="uniq at --gpus > 1")
     ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
@@ -215,8 +215,16 @@ def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
     of the same device-generated batch, next to the same restatement on one core; the GPU's output on the sample is
     compared byte for byte (uniq: also the first-seen indices)."""
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
-    S = min(N, args.cpu_sample if args.cpu_sample is not None else max(200_000, 20_000 * cores))
+    visible = len(os.sched_getaffinity(0))
+    quota = visible                 # the box's CPU share: a cgroup quota below the affinity mask makes extra threads fight for it
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, -(-int(q) // int(per)))
+    except (OSError, ValueError):
+        pass
+    cores = min(visible, quota)
+    S = min(N, args.cpu_sample if args.cpu_sample is not None else max(200_000, 100_000 * cores))
     if args.workload == "mixed":
         S = min(S, 100_000)                       # ~3.6 kb per record on average
         h_off = d_off[:S + 1].cpu().numpy().astype(np.uint64)
@@ -243,11 +251,11 @@ def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
     what = {"canonicalize": "normalize-free canonicalize", "uniq": "canonicalize + XXH3-64 on all cores, then the first-seen map on one "
             "thread (the reference's main-thread closure)", "mixed": "canonicalize"}[args.workload]
     return {
-        "value": S / cdt, "unit": "sequences/s", "cores": cores, "host_cores_visible": cores,
+        "value": S / cdt, "unit": "sequences/s", "cores": cores, "host_cores_visible": visible, "cgroup_cpu_quota": quota,
         "kind": "port", "one_core_value": one_core,
         "sample": "first %d records (%d bases) of the same device-generated batch; C restatement of the reference path: %s "
-                  "(linear-time byte-indexed Duval variant, faster than the reference's O(n^2) chars().nth() loop), %d pthreads; "
-                  "one_core_value on the first %d records" % (S, nb, what, cores, S1),
+                  "(linear-time byte-indexed Duval variant, faster than the reference's O(n^2) chars().nth() loop), %d pthreads = every core "
+                  "this process may use (%d visible, cgroup quota %d); one_core_value on the first %d records" % (S, nb, what, cores, visible, quota, S1),
         "gpu_output_matches": same,
     }
 

@@ -285,10 +285,13 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Two words per lane: records of 1009..2032 bases (the 1.0-1.7 kb circular RNAs -- obelisks, deltaviruses -- sit
-// here).  Lane t holds words 2t and 2t+1 (symbols [32t, 32t+32)); word q of a strand therefore lives in lane q>>1,
-// register q&1, and every cross-lane access goes through word2().  Same algorithm and exits as fast_canon; XXH3 by
-// fast_hash2 (two blocks with the scramble step between them).
+// Two words per lane.  BITS = 2: records of 1009..2032 bases (the 1.0-1.7 kb circular RNAs -- obelisks, deltaviruses
+// -- sit here), lane t = symbols [32t, 32t+32).  BITS = 4: records of 48..1008 symbols over the CLI alphabet
+// {-,A,C,G,N,T} -- the reference treats N and '-' like any other byte (lib/src/canonicalize.rs:50-53), and one N no
+// longer sends a 1 kb record to the LDS tiers -- lane t = symbols [16t, 16t+16).  Word q of a strand lives in lane
+// q>>1, register q&1, and every cross-lane access goes through word2().  Same algorithm and exits as fast_canon; keys
+// are one word = S = 32/BITS symbols (8 for BITS = 4: two positions share the minimal 8-mer in ~1 % of random 1 kb
+// records, which then take the LDS tier).  XXH3: fast_hash2 for BITS = 2; the 4-bit records leave theirs to the xxh3 pass.
 constexpr uint32_t FAST2_MAX_N = 2032;
 CK_DEV bool fast2_eligible(uint32_t n) { return n - (FAST_MAX_N + 1) <= FAST2_MAX_N - (FAST_MAX_N + 1); }
 
@@ -297,38 +300,58 @@ CK_DEV uint32_t word2(uint32_t W0, uint32_t W1, uint32_t q)
     const uint32_t a = shfl(W0, q >> 1), b = shfl(W1, q >> 1);
     return (q & 1) ? b : a;
 }
-CK_DEV uint32_t reg_sym_word2(uint32_t W0, uint32_t W1, uint32_t p, uint32_t n)    // p < 2n, lane-varying
+template <int BITS>
+CK_DEV uint32_t reg_sym_wordw(uint32_t W0, uint32_t W1, uint32_t p, uint32_t n)    // p < 2n, lane-varying
 {
+    constexpr uint32_t S = 32 / BITS;
     p = p >= n ? p - n : p;
-    const uint32_t wi = p >> 4;
-    return lshr64(word2(W0, W1, wi), word2(W0, W1, wi + 1), 32 - (p & 15) * 2);
+    const uint32_t wi = p / S;
+    return lshr64(word2(W0, W1, wi), word2(W0, W1, wi + 1), 32 - (p % S) * BITS);
 }
+CK_DEV uint32_t reg_sym_word2(uint32_t W0, uint32_t W1, uint32_t p, uint32_t n) { return reg_sym_wordw<2>(W0, W1, p, n); }
 // adds the valid positions of word 2l+k (l = first lane of hm) whose key equals M; cur / nxt = that register and the
-// word behind it, as lane vectors
+// word behind it, as lane vectors; shv = 32 - BITS * (lane & (S - 1))
+template <int BITS>
 CK_DEV void locate2_word(uint32_t cur, uint32_t nxt, uint32_t l, uint32_t k, uint32_t M, uint32_t n, uint32_t shv, uint32_t& cnt, uint32_t& pos)
 {
+    constexpr uint32_t S = 32 / BITS;
     const uint32_t w = 2 * l + k;
     const uint32_t key = lshr64(readlane(cur, l), readlane(nxt, l), shv);
-    const uint32_t left = n - 16 * w;
-    const uint32_t pm = (uint32_t)ballot(key == M) & (0xFFFFu >> (16 - (left < 16 ? left : 16)));
+    const uint32_t left = n - S * w;
+    const uint32_t pm = (uint32_t)ballot(key == M) & ((1u << (left < S ? left : S)) - 1u);     // lanes 0..S-1: the word's positions
     cnt += (uint32_t)popc64(pm);
-    if (pm) pos = 16 * w + (uint32_t)ffs64(pm);
+    if (pm) pos = S * w + (uint32_t)ffs64(pm);
 }
 // position of the minimal key M in a two-words-per-lane strand and whether exactly one valid position owns it; at
 // most two hit words are examined (the second is normally the wrapped duplicate behind the record end)
+template <int BITS>
 CK_DEV uint32_t fast2x_locate(uint32_t E0, uint32_t E1, uint32_t E0n, uint64_t hm0, uint64_t hm1, uint32_t M, uint32_t n, uint32_t shv,
                               bool& unique)
 {
     uint32_t cnt = 0, pos = 0;
     const uint32_t hits = (uint32_t)(popc64(hm0) + popc64(hm1));
-    if (hm0) locate2_word(E0, E1, (uint32_t)ffs64(hm0), 0, M, n, shv, cnt, pos);
-    if (hm1) locate2_word(E1, E0n, (uint32_t)ffs64(hm1), 1, M, n, shv, cnt, pos);
+    if (hm0) locate2_word<BITS>(E0, E1, (uint32_t)ffs64(hm0), 0, M, n, shv, cnt, pos);
+    if (hm1) locate2_word<BITS>(E1, E0n, (uint32_t)ffs64(hm1), 1, M, n, shv, cnt, pos);
     if (hits == 2 && (hm0 == 0 || hm1 == 0)) {            // both hits in the same register: its second lane
-        if (hm0) { hm0 &= hm0 - 1; locate2_word(E0, E1, (uint32_t)ffs64(hm0), 0, M, n, shv, cnt, pos); }
-        else { hm1 &= hm1 - 1; locate2_word(E1, E0n, (uint32_t)ffs64(hm1), 1, M, n, shv, cnt, pos); }
+        if (hm0) { hm0 &= hm0 - 1; locate2_word<BITS>(E0, E1, (uint32_t)ffs64(hm0), 0, M, n, shv, cnt, pos); }
+        else { hm1 &= hm1 - 1; locate2_word<BITS>(E1, E0n, (uint32_t)ffs64(hm1), 1, M, n, shv, cnt, pos); }
     }
     unique = cnt == 1 && hits <= 2;
     return pos;
+}
+
+// reverse complement of one packed word: symbol order reversed, every symbol complemented
+template <int BITS>
+CK_DEV uint32_t rc_word(uint32_t g)
+{
+    if (BITS == 2) {
+        const uint32_t v = bitrev(~g);                      // reverses bits; swap the two bits of every symbol back
+        return bfi(0x55555555u, v >> 1, v << 1);
+    }
+    // 4-bit codes '-'0 A1 C2 G3 N4 T5: complement by v_perm as an 8-entry table (0 5 3 2 4 1), the nibbles of a byte
+    // swapped while they are apart, then the bytes reversed
+    const uint32_t lo = perm(0x00000104u, 0x02030500u, g & 0x0F0F0F0Fu), hi = perm(0x00000104u, 0x02030500u, (g >> 4) & 0x0F0F0F0Fu);
+    return perm(0u, (lo << 4) | hi, 0x00010203u);
 }
 
 // XXH3-64 of a two-words-per-lane record (1009..2032 bytes: one or two 1024-byte blocks), fused like fast_hash: per
@@ -370,63 +393,71 @@ CK_DEV uint64_t fast_hash2(const FastHashConst& hc, const uint32_t* lut, uint32_
     return ((uint64_t)readlane((uint32_t)(h >> 32), 15) << 32) | readlane((uint32_t)h, 15);
 }
 
-// W0 / W1: lane t = symbols [32t, 32t+16) / [32t+16, 32t+32) of the record (garbage past n); bad = any lane of the
-// record's chunks holds a byte outside ACGT.
-template <bool HASH, bool AUX>
-CK_DEV bool fast_canon2(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
+// W0 / W1: lane t = words 2t / 2t+1 of the record (garbage past n); bad = any lane of the record's chunks holds a
+// byte outside the mode's alphabet.
+template <int BITS, bool HASH, bool AUX>
+CK_DEV bool fast_canonw(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
                         uint32_t W0, uint32_t W1, bool bad)
 {
+    static_assert(BITS == 2 || (BITS == 4 && !AUX), "4-bit records: canonical bytes only (index / strand requests take the LDS tier)");
+    constexpr uint32_t S = 32 / BITS;
     const uint32_t t = lane_id();
-    const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
+    const uint32_t nwf = n / S, r = n % S, nwv = nwf + (r ? 1u : 0u);
     const uint32_t w0 = 2 * t, w1 = 2 * t + 1;
     // periodic extension (words >= nwf), from the original words: E[nwf] = r tail symbols ++ head, E[nwv + e] = head
     // shifted by r.  Words up to index nwv are needed (scan of the last word, reverse strand); nwv <= 127.
     {
-        const uint32_t esh = 32 - ((16 - r) & 15) * 2;
+        const uint32_t esh = 32 - ((S - r) % S) * BITS;
         const uint32_t A0 = word2(W0, W1, w0 - nwv), B0 = word2(W0, W1, w0 - nwv + 1), B1 = word2(W0, W1, w1 - nwv + 1);
-        const uint32_t keep = ~(0xFFFFFFFFu >> (2 * r));
-        const uint32_t n0 = w0 >= nwv ? lshr64(A0, B0, esh) : (w0 == nwf ? bfi(keep, W0, B0 >> (2 * r)) : W0);
-        const uint32_t n1 = w1 >= nwv ? lshr64(B0, B1, esh) : (w1 == nwf ? bfi(keep, W1, B1 >> (2 * r)) : W1);   // word(w1-nwv) = B0
+        const uint32_t keep = ~(0xFFFFFFFFu >> (BITS * r));
+        const uint32_t n0 = w0 >= nwv ? lshr64(A0, B0, esh) : (w0 == nwf ? bfi(keep, W0, B0 >> (BITS * r)) : W0);
+        const uint32_t n1 = w1 >= nwv ? lshr64(B0, B1, esh) : (w1 == nwf ? bfi(keep, W1, B1 >> (BITS * r)) : W1);   // word(w1-nwv) = B0
         W0 = n0; W1 = n1;
     }
     const bool fwd_only = AUX && (a.flags & CK_FLAG_FWD_ONLY) != 0;
-    // reverse-complement strand: rc word w = comp(reverse(forward symbols [n - 16(w+1), n - 16w) mod n))
+    // reverse-complement strand: rc word w = comp(reverse(forward symbols [n - S(w+1), n - S w) mod n))
     uint32_t C0, C1;
     {
         uint32_t c[2];
 #pragma unroll
         for (uint32_t k = 0; k < 2; ++k) {
-            const int32_t p0 = (int32_t)n - 16 * (int32_t)(2 * t + k + 1);
+            const int32_t p0 = (int32_t)n - (int32_t)S * (int32_t)(2 * t + k + 1);
             const uint32_t p = (uint32_t)(p0 + ((p0 >> 31) & (int32_t)n));      // (garbage for words past nwv + 1: unused)
-            const uint32_t g = ~lshr64(word2(W0, W1, p >> 4), word2(W0, W1, (p >> 4) + 1), 32 - (p & 15) * 2);
-            const uint32_t v = bitrev(g);
-            c[k] = bfi(0x55555555u, v >> 1, v << 1);
+            c[k] = rc_word<BITS>(lshr64(word2(W0, W1, p / S), word2(W0, W1, p / S + 1), 32 - (p % S) * BITS));
         }
         C0 = c[0]; C1 = c[1];
     }
     const uint32_t W0n = wave_shl1(W0), C0n = wave_shl1(C0);          // word 2t+2 = the word behind register 1
     const bool v0 = w0 < nwv, v1 = w1 < nwv;
-    const uint32_t mF0 = v0 ? word_min_key<2>(W0, W1) : ~0u, mF1 = v1 ? word_min_key<2>(W1, W0n) : ~0u;
-    const uint32_t mC0 = v0 ? word_min_key<2>(C0, C1) : ~0u, mC1 = v1 ? word_min_key<2>(C1, C0n) : ~0u;
+    const uint32_t mF0 = v0 ? word_min_key<BITS>(W0, W1) : ~0u, mF1 = v1 ? word_min_key<BITS>(W1, W0n) : ~0u;
+    const uint32_t mC0 = v0 ? word_min_key<BITS>(C0, C1) : ~0u, mC1 = v1 ? word_min_key<BITS>(C1, C0n) : ~0u;
     uint32_t MF, MC;
     wave_min2_u32(mF0 < mF1 ? mF0 : mF1, mC0 < mC1 ? mC0 : mC1, MF, MC);
     const bool fwd = fwd_only || MF <= MC;
     const bool tie = !fwd_only && MF == MC;
-    const uint32_t shv = 32 - 2 * (t & 15);
+    const uint32_t shv = 32 - BITS * (t & (S - 1));
     const uint32_t E0 = fwd ? W0 : C0, E1 = fwd ? W1 : C1;
     bool uE, uF = true;
-    const uint32_t idx = fwd ? fast2x_locate(W0, W1, W0n, ballot(mF0 == MF), ballot(mF1 == MF), MF, n, shv, uE)
-                             : fast2x_locate(C0, C1, C0n, ballot(mC0 == MC), ballot(mC1 == MC), MC, n, shv, uE);
+    const uint32_t idx = fwd ? fast2x_locate<BITS>(W0, W1, W0n, ballot(mF0 == MF), ballot(mF1 == MF), MF, n, shv, uE)
+                             : fast2x_locate<BITS>(C0, C1, C0n, ballot(mC0 == MC), ballot(mC1 == MC), MC, n, shv, uE);
     uint32_t iF = idx;
-    if (AUX && a.out_index && !fwd) iF = fast2x_locate(W0, W1, W0n, ballot(mF0 == MF), ballot(mF1 == MF), MF, n, shv, uF);
+    if (AUX && a.out_index && !fwd) iF = fast2x_locate<BITS>(W0, W1, W0n, ballot(mF0 == MF), ballot(mF1 == MF), MF, n, shv, uF);
     if (bad || tie || !uE || !uF) return false;
-    const bool hash = HASH && a.out_hash != nullptr;
+    const bool hash = BITS == 2 && HASH && a.out_hash != nullptr;
     if (a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL))) {
+        if (BITS == 2) {
 #pragma unroll
-        for (uint32_t k = 0; k < 2; ++k) {
-            // every stored window is a full 16 bytes: the record's last window is pulled back to end exactly at n
-            const uint32_t ob = 32 * t + 16 * k, o = ob + 16 <= n ? ob : n - 16;
-            const u32x4 cell = fast_decode(lut, reg_sym_word2(E0, E1, idx + o, n));
+            for (uint32_t k = 0; k < 2; ++k) {
+                // every stored window is a full 16 bytes: the record's last window is pulled back to end exactly at n
+                const uint32_t ob = 32 * t + 16 * k, o = ob + 16 <= n ? ob : n - 16;
+                const u32x4 cell = fast_decode(lut, reg_sym_wordw<2>(E0, E1, idx + o, n));
+                if (ob < n) store16(a.out_bytes + off + o, cell);
+            }
+        } else {
+            const uint32_t ob = 16 * t, o = ob + 16 <= n ? ob : n - 16;
+            u32x4 cell;
+            decode4(reg_sym_wordw<4>(E0, E1, idx + o, n), cell.x, cell.y);
+            decode4(reg_sym_wordw<4>(E0, E1, idx + o + 8, n), cell.z, cell.w);
             if (ob < n) store16(a.out_bytes + off + o, cell);
         }
     }
@@ -439,6 +470,20 @@ CK_DEV bool fast_canon2(const CanonArgs& a, const uint32_t* lut, const FastHashC
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
     return true;
+}
+template <bool HASH, bool AUX>
+CK_DEV bool fast_canon2(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, uint32_t rec, uint64_t off, uint32_t n,
+                        uint32_t W0, uint32_t W1, bool bad)
+{
+    return fast_canonw<2, HASH, AUX>(a, lut, hc, rec, off, n, W0, W1, bad);
+}
+
+// 16 ASCII bytes -> two 4-bit words (symbols [0,8) and [8,16)); bad != 0 iff a byte is outside {-,A,C,G,N,T}
+CK_DEV void fast_pack4(u32x4 v, uint32_t& H, uint32_t& L, uint32_t& bad)
+{
+    bad = 0;
+    H = pack4_fwd(v.x, v.y, bad);
+    L = pack4_fwd(v.z, v.w, bad);
 }
 
 }  // namespace ck

@@ -218,10 +218,21 @@ CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, Rescue
         bool done = false;
         if (len <= FAST_MAX_N && fast_eligible((uint32_t)len)) {
             const uint32_t n = (uint32_t)len, nwf = n >> 4;
+            const u32x4 v = load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t));
+            const uint32_t tail_syms = t >= nwf ? (16 - (n & 15)) & 15 : 0;       // the tail lane's symbols move up by this much
             uint32_t miss;
-            uint32_t F = fast_pack(load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t)), miss);
-            F <<= t >= nwf ? ((16 - (n & 15)) & 15) * 2 : 0;
-            done = fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F, ballot(miss != 0));
+            const uint32_t F = fast_pack(v, miss);
+            const uint64_t bad = ballot(miss != 0);
+            if (AUX || bad == 0) {
+                done = fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F << (2 * tail_syms), bad);
+            } else {
+                // a byte outside ACGT: the CLI alphabet {-,A,C,G,N,T} at 4 bits per symbol, two words per lane, still in
+                // registers (builds that report index / strand leave these records to the LDS tiers)
+                uint32_t H, L, bad4;
+                fast_pack4(v, H, L, bad4);
+                const uint64_t x = ((((uint64_t)H) << 32) | L) << (4 * tail_syms);
+                done = fast_canonw<4, HASH, false>(a, lut, st.hc, rec, off, n, (uint32_t)(x >> 32), (uint32_t)x, ballot(bad4 != 0) != 0);
+            }
         }
         if (!done) defer_record(a, seg_count, seg_index, rec);
     }

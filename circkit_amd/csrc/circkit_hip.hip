@@ -35,18 +35,23 @@ namespace {
 // One wavefront per record, WPB wavefronts per workgroup, each with its own LDS slice; the last LDS dword is the
 // workgroup's deferral counter.  Consumes the segmented list of the previous stage (or all records).
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a)
+__global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32_t nvb)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + WPB * a.slice_dw;
     uint32_t* lut = blk_count + 4;                   // 2-bit decode table shared by the workgroup's waves
     ck::fast_lut_init(lut, threadIdx.x, WPB * 64);
-    if (threadIdx.x == 0) *blk_count = 0;
-    __syncthreads();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
-    ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, blockIdx.x, gridDim.x, wib, WPB);
-    __syncthreads();
-    if (threadIdx.x == 0 && a.defer_count) a.defer_count[blockIdx.x] = *blk_count;
+    // `nvb` virtual workgroups (one output segment each) walked by a grid that is no bigger than what keeps the chip
+    // busy: on the batches where these tiers have nothing to do (the headline) one workgroup per segment was 12-28 us of
+    // pure dispatch per tier
+    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        if (threadIdx.x == 0) *blk_count = 0;
+        __syncthreads();
+        ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, vb, nvb, wib, WPB);
+        __syncthreads();
+        if (threadIdx.x == 0 && a.defer_count) a.defer_count[vb] = *blk_count;
+    }
 }
 
 // The end of the line: records no LDS tier can hold (2-bit beyond ~260 kb).  Same code, one wave per record, with the
@@ -100,18 +105,26 @@ using StreamCAux2 = ck::StreamCfg<4, 2, 2, 2>;
 // slower, the longer ones 1.5x faster than LDS tier A; at 15 % -- BASELINE config 4 -- it measured 2 % slower overall).
 // count[0..1] must be 0 on entry.  The decision is taken again for EVERY batch from the batch's own offsets (an
 // earlier version remembered it per offsets pointer, which a host that reuses one offsets buffer defeats).
-__global__ __launch_bounds__(256) void stream_count_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* count)
+__global__ __launch_bounds__(1024) void stream_count_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* count)
 {
+    __shared__ uint32_t blk[2];
+    if (threadIdx.x < 2) blk[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t two = 0, lng = 0;          // records of 1009..2032 bases / longer ones (no build can stage their group)
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 1024) {
         const uint64_t len = offsets[i + 1] - offsets[i];
         two += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
         lng += len > ck::FAST2_MAX_N;
     }
-    if (ck::ballot(two | lng) == 0) return;                    // the common batch: nothing to add
-    const uint64_t t2 = ck::wave_sum_u64(two), tl = ck::wave_sum_u64(lng);
-    if (ck::lane_id() == 0 && t2) atomicAdd(count, (uint32_t)t2);
-    if (ck::lane_id() == 0 && tl) atomicAdd(count + 1, (uint32_t)tl);
+    // one global atomic per workgroup and counter, and none for the common batch: thousands of waves adding to the
+    // same two words serialise at ~10 ns each (measured: 188 us on BASELINE config 4 with one atomic per wave)
+    if (ck::ballot(two | lng) != 0) {
+        const uint64_t t2 = ck::wave_sum_u64(two), tl = ck::wave_sum_u64(lng);
+        if (ck::lane_id() == 0 && t2) atomicAdd(&blk[0], (uint32_t)t2);
+        if (ck::lane_id() == 0 && tl) atomicAdd(&blk[1], (uint32_t)tl);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && blk[threadIdx.x]) atomicAdd(count + threadIdx.x, blk[threadIdx.x]);
 }
 // 1 / 2: which build of the streaming kernel; 3: neither -- with one record in eight longer than 2032 bases at most
 // 12 % of the 16-record groups could be staged, and the rescue pass takes every record straight away
@@ -347,6 +360,9 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #ifndef CK_RESCUE_BPC
 #define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
 #endif
+#ifndef CK_TIER_BPC
+#define CK_TIER_BPC 32     // workgroups launched per CU by the LDS tiers (they walk the list segments)
+#endif
 #ifndef CK_TIER_KEEP
 #define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
 #endif
@@ -515,7 +531,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             if (c->mode_pending && hipEventQuery(c->mode_ev) == hipSuccess) { c->mode_hint = *c->h_mode; c->mode_pending = false; }
             else (void)hipGetLastError();          // hipErrorNotReady is not an error of this call
             CK_HIP(c, hipMemsetAsync(c->d_counters + 6, 0, 8, c->stream));
-            hipLaunchKernelGGL(stream_count_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_offsets, n, c->d_counters + 6);
+            hipLaunchKernelGGL(stream_count_kernel, dim3(N_CU * 2), dim3(1024), 0, c->stream, d_offsets, n, c->d_counters + 6);
         }
         const uint32_t expect = host_mode ? host_mode : c->mode_hint;
         const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
@@ -561,8 +577,10 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 2) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
         a.slice_dw = TIER_DW[t];
-        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(grid), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a);
-        else hipLaunchKernelGGL(canon_kernel<1>, dim3(grid), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a);
+        // `grid` virtual workgroups; launched: a few times what is resident at once (dispatch order balances the rest)
+        const unsigned launched = grid < (unsigned)N_CU * CK_TIER_BPC ? grid : (unsigned)N_CU * CK_TIER_BPC;
+        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid);
+        else hipLaunchKernelGGL(canon_kernel<1>, dim3(launched), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid);
         nseg = grid;
         seg_cap = spb * seg_cap;
     }
@@ -611,7 +629,7 @@ int launch_single(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
     while (t < N_TIERS && TIER_DW[t] < need) ++t;
     if (t < N_TIERS) {
         a.slice_dw = TIER_DW[t];
-        hipLaunchKernelGGL(canon_kernel<1>, dim3(1), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a);
+        hipLaunchKernelGGL(canon_kernel<1>, dim3(1), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, 1u);
     } else {
         int rc = ensure_gscratch(c, need * 4);
         if (rc) return rc;

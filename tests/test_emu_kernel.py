@@ -187,14 +187,14 @@ def test_rescue_pass_takes_short_records_of_unstaged_groups():
         block = seqsets.random_mixed(981 + g, 15, 100, 1008)
         block.insert(int(rng.integers(0, 16)), seqsets.random_mixed(990 + g, 1, 30000, 30000)[0])
         seqs += block
-    seqs += seqsets.random_mixed(999, 5, 100, 900, b"ACGTN")            # not eligible: must reach the tiers
+    seqs += seqsets.random_mixed(999, 5, 100, 900, b"ACGTN")            # 4-bit register path, unless index / strand are asked for
     data, offs = seqsets.pack(seqs)
     want = [seqsets.expected(O, s) for s in seqs]
     for want_hash, want_aux in ((False, False), (True, False), (True, True)):
         out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=want_hash, want_aux=want_aux, staged=1,
                                                                    slice_dw=8192, n_waves=24)
         assert emu.last_fast_count == 0                                  # no group could be staged
-        assert emu.last_rescued_count == 6 * 15
+        assert emu.last_rescued_count == 6 * 15 + (0 if want_aux else 5)
         for i, s in enumerate(seqs):
             a, b = int(offs[i]), int(offs[i + 1])
             assert out[a:b].tobytes() == want[i][0], (i, len(s))
@@ -224,3 +224,31 @@ def test_mode_3_rescue_pass_takes_every_record():
                 assert int(h[i]) == O.xxh3_64(want[i][0])
             if want_aux and len(s):
                 assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2])
+
+
+def test_four_bit_register_path_takes_n_and_gap_records():
+    """Records over {-,A,C,G,N,T} of 48..1008 symbols: two 4-bit words per lane in registers (fast_canonw<4>) instead of
+    the LDS tiers -- every length class of the periodic extension, sparse and dense N, '-' (sorts below A), runs."""
+    rng = np.random.default_rng(1100)
+    seqs = []
+    for L in list(range(48, 80)) + [127, 128, 129, 255, 256, 257, 511, 512, 513, 999, 1000, 1001, 1006, 1007, 1008]:
+        s = bytearray(seqsets.random_mixed(1101 + L, 1, L, L)[0])
+        for p in rng.integers(0, L, size=max(1, L // 100)):
+            s[int(p)] = ord("N")
+        seqs.append(bytes(s))
+    seqs += seqsets.random_mixed(1102, 60, 48, 1008, b"ACGTN") + seqsets.random_mixed(1103, 40, 48, 1008, b"ACGTN-")
+    seqs += [b"N" * 100, b"ACGTN" * 60, b"-" * 50 + b"A" * 50, b"A" * 999 + b"N", b"N" + b"T" * 600, b"ACGT" * 100 + b"-"]
+    one_n = bytearray(seqsets.random_mixed(1104, 1, 1000, 1000)[0])
+    one_n[500] = ord("N")
+    seqs.append(bytes(one_n))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    for staged, want_hash in ((0, False), (0, True), (1, False)):
+        out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=want_hash, want_aux=False, staged=staged,
+                                                                   slice_dw=4096, n_waves=12)
+        assert emu.last_rescued_count >= len(seqs) - 12                  # all but periodic records / ties on the 8-symbol key
+        for i, s in enumerate(seqs):
+            a, b = int(offs[i]), int(offs[i + 1])
+            assert out[a:b].tobytes() == want[i][0], (i, len(s), s[:40])
+            if want_hash:
+                assert int(h[i]) == O.xxh3_64(want[i][0])
