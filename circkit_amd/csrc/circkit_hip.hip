@@ -35,7 +35,7 @@ namespace {
 // One wavefront per record, WPB wavefronts per workgroup, each with its own LDS slice; the last LDS dword is the
 // workgroup's deferral counter.  Consumes the segmented list of the previous stage (or all records).
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32_t nvb)
+__global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32_t nvb, uint32_t* giants)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + WPB * a.slice_dw;
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32
         ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, vb, nvb, wib, WPB);
         __syncthreads();
         if (threadIdx.x == 0 && a.defer_count) a.defer_count[vb] = *blk_count;
+        if (threadIdx.x == 0 && giants && *blk_count) atomicAdd(giants, *blk_count);     // last LDS tier: tell the global-scratch kernel there is work
     }
 }
 
@@ -58,15 +59,48 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32
 // packed strands and the candidate bitmask in a slice of GLOBAL scratch instead of LDS.  The lanes of one wavefront
 // hand data to each other through that memory; wave_sync()'s wavefront-scope fences are what the AMDGPU memory model
 // asks for there (one wave, one L1, in-order vector memory), so canon_core.h runs unchanged.
-__global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, uint32_t* scratch)
+// One launch, two phases.  Phase 1: every workgroup (one wave) takes its share of the input segments with a slice of the
+// scratch; what still does not fit goes to its output segment.  Phase 2: the workgroup that finishes LAST (arrival
+// ticket) takes all output segments with the WHOLE scratch -- by then nobody else uses it.  The hand-over of the
+// lists between workgroups follows the agent-scope release / acquire recipe (cdna_hip_programming.md, Guideline 16):
+// stores drained, release fence, ticket; the last arriver acquires before it reads.  a2 = the arguments of phase 2.
+__global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::CanonArgs a2, uint32_t* scratch, uint32_t* ticket, const uint32_t* giants)
 {
-    __shared__ uint32_t blk_count, lut[256];
+    if (*giants == 0) return;           // nothing came out of the last LDS tier (every ordinary batch): the launch costs ~3 us, not ~12
+    __shared__ uint32_t blk_count, lut[256], last;
     ck::fast_lut_init(lut, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
     ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1);
     __syncthreads();
-    if (threadIdx.x == 0 && a.defer_count) a.defer_count[blockIdx.x] = blk_count;      // the next stage reads every segment's count
+    if (threadIdx.x == 0) {
+        a.defer_count[blockIdx.x] = blk_count;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t arrived = atomicAdd(ticket, 1u);
+        last = arrived == gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *ticket = 0;                                    // ready for the next batch
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) blk_count = 0;
+    __syncthreads();
+    ck::canon_wave_loop(a2, scratch, lut, &blk_count, 0, 1, 0, 1);           // no output list: leftovers are counted in status[0]
+}
+
+// one record in global scratch (the host API's single-record calls)
+__global__ __launch_bounds__(64) void canon_global_one_kernel(ck::CanonArgs a, uint32_t* scratch)
+{
+    __shared__ uint32_t blk_count, lut[256];
+    ck::fast_lut_init(lut, threadIdx.x, 64);
+    if (threadIdx.x == 0) blk_count = 0;
+    __syncthreads();
+    ck::canon_wave_loop(a, scratch, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1);
 }
 
 // XXH3-64 of the listed records (the ones canon_global_kernel finished after the batch's own hash pass)
@@ -103,18 +137,53 @@ using StreamCAux2 = ck::StreamCfg<4, 2, 2, 2>;
 
 // The ROWS = 2 build is used when at least 1 record in 4 is a 1009..2032-base one (it runs the shorter records 4-6 %
 // slower, the longer ones 1.5x faster than LDS tier A; at 15 % -- BASELINE config 4 -- it measured 2 % slower overall).
-// count[0..1] must be 0 on entry.  The decision is taken again for EVERY batch from the batch's own offsets (an
-// earlier version remembered it per offsets pointer, which a host that reuses one offsets buffer defeats).
-__global__ __launch_bounds__(1024) void stream_count_kernel(const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* count)
+// The decision is taken again for EVERY batch from the batch's own offsets (an earlier version remembered it per
+// offsets pointer, which a host that reuses one offsets buffer defeats) -- from a SAMPLE of them: every mode computes
+// the same results, the choice only has to be right about which is fastest, and reading all 80 MB of a 10M-record
+// batch's offsets cost 16-21 us per batch.  Every 2^count_shift(n)-th record is looked at (<= 128k of them).
+__host__ __device__ inline uint32_t count_shift(uint64_t n) { return n <= (1u << 17) ? 0u : (uint32_t)(63 - __builtin_clzll(n)) - 16u; }
+__host__ __device__ inline uint64_t count_samples(uint64_t n) { return (n + (1ull << count_shift(n)) - 1) >> count_shift(n); }
+// 1 / 2: which build of the streaming kernel; 3: neither -- with one record in eight longer than 2032 bases at most
+// 12 % of the 16-record groups could be staged, and the rescue pass takes every record straight away
+__host__ __device__ inline uint32_t stream_mode(uint64_t two, uint64_t lng, uint64_t n)
 {
-    __shared__ uint32_t blk[2];
-    if (threadIdx.x < 2) blk[threadIdx.x] = 0;
+    return lng && lng * 8 >= n ? 3u : (two && two * 4 >= n ? 2u : 1u);
+}
+// The same kernel samples the CONTENT: up to CONTENT_SAMPLES evenly spaced records, a wave each, first 1008 bytes -- does
+// the record hold a byte outside ACGT?  With one sampled record in 16 (or more) doing so, the batch's mode carries
+// MODE_ALPHA and the rescue pass runs its build with the 4-bit register path (canon_stream.h); otherwise the lean build,
+// which leaves the odd N-bearing record to the LDS tiers (carrying the 4-bit path costs the lean one 25-45 %, measured).
+constexpr uint32_t CONTENT_SAMPLES = 4096, MODE_ALPHA = 4;
+__host__ __device__ inline uint32_t alpha_mode(uint64_t bad, uint64_t sampled) { return bad && bad * 16 >= sampled ? MODE_ALPHA : 0u; }
+// ctl: [0] two-word records among the samples, [1] longer ones, [2] arrival ticket, [3] content samples with a byte
+// outside ACGT -- all zero on entry and on exit; *mode receives stream_mode() | alpha_mode() of the samples (written by
+// the workgroup that arrives last), counters[0] (records beyond the LDS tiers) and counters[3] (records nothing could
+// take) are zeroed: nothing of this batch has touched them yet, nothing of the previous one is still running.
+__global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* ctl,
+                                                            uint32_t* mode, uint32_t* counters)
+{
+    __shared__ uint32_t blk[3];
+    if (threadIdx.x < 3) blk[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 3) { counters[0] = 0; counters[3] = 0; }
     __syncthreads();
+    const uint32_t shift = count_shift(n);
+    const uint64_t ns = count_samples(n);
     uint32_t two = 0, lng = 0;          // records of 1009..2032 bases / longer ones (no build can stage their group)
-    for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 1024) {
+    for (uint64_t j = (uint64_t)blockIdx.x * 1024 + threadIdx.x; j < ns; j += (uint64_t)gridDim.x * 1024) {
+        const uint64_t i = j << shift;
         const uint64_t len = offsets[i + 1] - offsets[i];
         two += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
         lng += len > ck::FAST2_MAX_N;
+    }
+    // content samples: record k * cstep, one wave each
+    const uint64_t nc = n < CONTENT_SAMPLES ? n : CONTENT_SAMPLES, cstep = n / nc;
+    uint32_t bad = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * 16 + (threadIdx.x >> 6); k < nc; k += (uint64_t)gridDim.x * 16) {
+        const uint64_t off = offsets[k * cstep], len = offsets[k * cstep + 1] - off;
+        const uint32_t m = len < ck::FAST_MAX_N ? (uint32_t)len : ck::FAST_MAX_N, t = ck::lane_id();
+        uint32_t miss = 0;
+        if (m >= 16 && 16 * t < m) (void)ck::fast_pack(ck::load16(bytes + off + (16 * t + 16 <= m ? 16 * t : m - 16)), miss);
+        bad += ck::ballot(miss != 0) != 0;
     }
     // one global atomic per workgroup and counter, and none for the common batch: thousands of waves adding to the
     // same two words serialise at ~10 ns each (measured: 188 us on BASELINE config 4 with one atomic per wave)
@@ -123,30 +192,40 @@ __global__ __launch_bounds__(1024) void stream_count_kernel(const uint64_t* __re
         if (ck::lane_id() == 0 && t2) atomicAdd(&blk[0], (uint32_t)t2);
         if (ck::lane_id() == 0 && tl) atomicAdd(&blk[1], (uint32_t)tl);
     }
+    if (ck::lane_id() == 0 && bad) atomicAdd(&blk[2], bad);
     __syncthreads();
-    if (threadIdx.x < 2 && blk[threadIdx.x]) atomicAdd(count + threadIdx.x, blk[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        if (blk[0]) atomicAdd(ctl, blk[0]);
+        if (blk[1]) atomicAdd(ctl + 1, blk[1]);
+        if (blk[2]) atomicAdd(ctl + 3, blk[2]);
+        // arrival ticket: the adds above are device-scope atomics (performed at the memory side, in order behind this
+        // wave's earlier ones once drained), the last arriver reads the sums with atomics as well
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(ctl + 2, 1u) == gridDim.x - 1) {
+            const uint32_t t2 = atomicExch(ctl, 0u), tl = atomicExch(ctl + 1, 0u), tb = atomicExch(ctl + 3, 0u);
+            *mode = stream_mode(t2, tl, ns) | alpha_mode(tb, nc);
+            atomicExch(ctl + 2, 0u);
+        }
+    }
 }
-// 1 / 2: which build of the streaming kernel; 3: neither -- with one record in eight longer than 2032 bases at most
-// 12 % of the 16-record groups could be staged, and the rescue pass takes every record straight away
-__host__ __device__ inline uint32_t stream_mode(uint64_t two, uint64_t lng, uint64_t n)
+// every kernel of a batch takes the mode from the same word (or the host's answer): bits 0..1 = stream_mode, MODE_ALPHA
+__device__ __forceinline__ uint32_t batch_mode(const uint32_t* __restrict__ mode, uint32_t host_mode)
 {
-    return lng && lng * 8 >= n ? 3u : (two && two * 4 >= n ? 2u : 1u);
-}
-// every kernel of a batch derives the mode from the same two counters (or takes the host's answer)
-__device__ __forceinline__ uint32_t batch_mode(const uint32_t* __restrict__ counts, uint32_t host_mode, uint64_t n)
-{
-    return host_mode ? host_mode : stream_mode(counts[0], counts[1], n);
+    return host_mode ? host_mode : *mode;
 }
 // Rescue pass (canon_stream.h): the streaming kernel's leftovers that are eligible by themselves, one wave per record.
 // A small persistent grid walks the list segments (a batch the streaming kernel handled completely leaves them
 // empty: the pass then costs a microsecond, not the dispatch of one workgroup per segment); segment s of the input
 // list yields segment s of the output list, so the tiers behind keep their geometry.
-template <bool HASH, bool AUX>
-__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, const uint32_t* __restrict__ counts, uint32_t host_mode, uint32_t* mode_out)
+// ALPHA: the build with the 4-bit register path and the prefetching loop, for batches whose mode carries MODE_ALPHA
+// (builds with index / strand outputs exist only as ALPHA = false: their N-bearing records take the LDS tiers).
+template <bool HASH, bool AUX, bool ALPHA>
+__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out)
 {
-    const uint32_t mode = batch_mode(counts, host_mode, a.n_records);
+    const uint32_t mode = batch_mode(mode_word, host_mode);
+    if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
-    const bool all_records = mode == 3;                                 // the streaming kernel stood this batch out
+    const bool all_records = (mode & 3) == 3;                           // the streaming kernel stood this batch out
     __shared__ uint32_t lut[256], seg_count;
     ck::fast_lut_init(lut, threadIdx.x, 256);
     ck::RescueState<HASH, AUX> st;
@@ -155,25 +234,27 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
         if (threadIdx.x == 0) seg_count = 0;
         __syncthreads();
-        ck::canon_rescue_segment<HASH, AUX>(a, lut, st, &seg_count, sgm, wib, 4, all_records);
+        ck::canon_rescue_segment<HASH, AUX, ALPHA>(a, lut, st, &seg_count, sgm, wib, 4, all_records);
         __syncthreads();
         if (threadIdx.x == 0) a.defer_count[sgm] = seg_count;
     }
 }
 
-// `nvb` virtual workgroups (one list segment each) are walked by the launched ones: the build the host expects to
-// match the batch is launched with one workgroup per virtual one, the other build with a small grid -- its
-// workgroups normally return at once, and take the whole batch when the expectation was wrong.
 // GH: the fused XXH3 is finished per 16-record group by one wave (canon_fast.h group_hash_*): 18.2 KiB more LDS, which
 // the ROWS = 2 build cannot afford next to its 64 KiB of images (two workgroups per CU are what matters most).
 #ifndef CK_GROUP_HASH
 #define CK_GROUP_HASH 1
 #endif
-template <class StreamC, bool HASH, bool AUX>
-__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ counts,
+// PERSIST = false: one workgroup per list segment (the build the host expects to match the batch, at full size).
+// PERSIST = true: `nvb` virtual workgroups walked by a small grid -- the OTHER build, whose workgroups normally return
+// at once (4-5 us instead of the ~40 us a full-size idle grid costs) and take the whole batch when the expectation was
+// wrong.  Two instantiations because the loop over virtual workgroups costs the hot path scalar registers (measured:
+// +2 % on the headline with one kernel for both).
+template <class StreamC, bool HASH, bool AUX, bool PERSIST>
+__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
                                                                                                              uint32_t host_mode, uint32_t nvb)
 {
-    if (batch_mode(counts, host_mode, a.n_records) != (uint32_t)StreamC::ROWS) return;    // the other build (or none) has this batch
+    if ((batch_mode(mode, host_mode) & 3) != (uint32_t)StreamC::ROWS) return;    // the other build (or none) has this batch
     constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && StreamC::RPW == 1 && StreamC::GROUP == 16;
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<16>() : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
@@ -181,6 +262,14 @@ __global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE
     uint32_t* gh = lds + StreamC::LDS_DW;
     ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
     if (GH) ck::group_hash_init(gh + 2 * 16 * ck::GH_STRIDE_DW, threadIdx.x);
+    if (!PERSIST) {
+        if (threadIdx.x == 0) *blk_count = 0;
+        __syncthreads();
+        ck::canon_stream_wave_loop<StreamC, HASH, AUX, GH>(a, lut, lds, blk_count, blockIdx.x, gridDim.x, gh);
+        __syncthreads();
+        if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
+        return;
+    }
     for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
@@ -340,10 +429,11 @@ __global__ __launch_bounds__(256) void uniq_rehash_kernel(const UniqSlot* __rest
     }
 }
 
-// every slot = {EMPTY, EMPTY}: 16 bytes per thread and trip
-__global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t slots)
+// every slot = {EMPTY, EMPTY}: 16 bytes per thread and trip; also zeroes the overflow counter
+__global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t slots, uint32_t* overflow)
 {
     typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride)
         *reinterpret_cast<v2*>(t + i) = v2{ UNIQ_EMPTY, UNIQ_EMPTY };
@@ -361,7 +451,7 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
 #endif
 #ifndef CK_TIER_BPC
-#define CK_TIER_BPC 32     // workgroups launched per CU by the LDS tiers (they walk the list segments)
+#define CK_TIER_BPC 128    // workgroups launched per CU by the LDS tiers at most (they walk the list segments); 128 = one per segment
 #endif
 #ifndef CK_TIER_KEEP
 #define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
@@ -408,10 +498,8 @@ struct circkit_ctx {
     uint32_t* d_gscratch = nullptr; uint64_t cap_gscratch = 0;    // bytes
     uint64_t gscratch_default = 256ull << 20;
     // the previous batch's mode (1 / 2 / 3, see stream_mode): only picks which build gets the full-size grid
-    uint32_t* h_mode = nullptr;          // pinned; d_counters[5] of the most recent batch, copied back behind it
-    hipEvent_t mode_ev = nullptr;
-    bool mode_pending = false;
-    uint32_t mode_hint = 1;
+    volatile uint32_t* h_mode = nullptr; // pinned host word the rescue kernel writes the batch's mode to (d_mode = its device address)
+    uint32_t* d_mode = nullptr;
     // uniq table
     UniqSlot* d_table = nullptr;         // [uniq_mask + 2]
     uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
@@ -474,6 +562,9 @@ constexpr uint64_t GSLICE1_DW = 1ull << 20;     // stage 1 of the global-scratch
 int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out,
                  uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags, uint32_t host_mode = 0)
 {
+#ifdef CK_FORCE_HOST_MODE
+    if (!host_mode) host_mode = CK_FORCE_HOST_MODE;      // experiment: no count kernel, no second build
+#endif
     if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
@@ -510,8 +601,11 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         }
         CK_HIP(c, hipMemsetAsync(c->d_hashed, 0, n, c->stream));
     }
-    // d_counters: [3] records nothing could take, [4] uniq table overflow, [5] the batch's mode, [6..7] length counts
-    CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    // d_counters: [0] records the last LDS tier passed on, [2] arrival ticket of the global-scratch kernel (leaves it zero),
+    // [3] records nothing could take, [4] uniq table overflow,
+    // [5] the batch's mode (device-side decision), [8..10] the count kernel's counters and ticket (it leaves them zero).
+    // A device-side decision zeroes [0] and [3] in its count kernel; the host-side one with a memset.
+    if (host_mode) CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
@@ -521,33 +615,41 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.list = nullptr; a.list_count = nullptr;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
-    const uint32_t* counts = c->d_counters + 6;
+    const uint32_t* counts = c->d_counters + 5;     // the mode word
     {
         // three builds of the streaming kernel: canonical bytes only (the headline), + fused XXH3 (uniq), and the
         // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr);
         // each for ROWS = 1 and ROWS = 2.  The host's answer launches exactly one of the two; a device-side decision
         // launches both, full-size where the previous batch's mode says it will run.
         if (!host_mode) {
-            if (c->mode_pending && hipEventQuery(c->mode_ev) == hipSuccess) { c->mode_hint = *c->h_mode; c->mode_pending = false; }
-            else (void)hipGetLastError();          // hipErrorNotReady is not an error of this call
-            CK_HIP(c, hipMemsetAsync(c->d_counters + 6, 0, 8, c->stream));
-            hipLaunchKernelGGL(stream_count_kernel, dim3(N_CU * 2), dim3(1024), 0, c->stream, d_offsets, n, c->d_counters + 6);
+            const uint64_t ns = count_samples(n);
+            const unsigned cgrid = (unsigned)((ns + 1023) / 1024 < 128 ? (ns + 1023) / 1024 : 128);
+            hipLaunchKernelGGL(stream_count_kernel, dim3(cgrid), dim3(1024), 0, c->stream, d_bytes, d_offsets, n, c->d_counters + 8, c->d_counters + 5, c->d_counters);
         }
-        const uint32_t expect = host_mode ? host_mode : c->mode_hint;
+        // the mode of whichever earlier batch last reported: a hint for the grid sizes, nothing else
+        const uint32_t seen = *c->h_mode;
+        const uint32_t expect = host_mode ? host_mode & 3 : ((seen & 3) ? seen & 3 : 1u);
         const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
         const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64);
         for (uint32_t rows = 1; rows <= 2; ++rows) {
-            if (host_mode && host_mode != rows) continue;
-            const dim3 grid(expect == rows ? G : small);
+            if (host_mode && (host_mode & 3) != rows) continue;
+            const bool full = expect == rows;            // full-size grid, one workgroup per segment; else the small walking grid
+            const dim3 grid(full ? G : small);
+#define CK_LAUNCH_STREAM(CFG, H, A, BLK)                                                                                         \
+            do {                                                                                                                \
+                if (full) hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, false>), grid, BLK, 0, c->stream, a, counts, host_mode, G); \
+                else hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, true>), grid, BLK, 0, c->stream, a, counts, host_mode, G);       \
+            } while (0)
             if (rows == 1) {
-                if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux, true, true>), grid, block_aux, 0, c->stream, a, counts, host_mode, G);
-                else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC, true, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
-                else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
+                if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux);
+                else if (d_hash) CK_LAUNCH_STREAM(StreamC, true, false, block);
+                else CK_LAUNCH_STREAM(StreamC, false, false, block);
             } else {
-                if (aux) hipLaunchKernelGGL((canon_stream_kernel<StreamCAux2, true, true>), grid, block_aux, 0, c->stream, a, counts, host_mode, G);
-                else if (d_hash) hipLaunchKernelGGL((canon_stream_kernel<StreamC2, true, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
-                else hipLaunchKernelGGL((canon_stream_kernel<StreamC2, false, false>), grid, block, 0, c->stream, a, counts, host_mode, G);
+                if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux);
+                else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block);
+                else CK_LAUNCH_STREAM(StreamC2, false, false, block);
             }
+#undef CK_LAUNCH_STREAM
         }
     }
     unsigned nseg = G;              // segments / capacity of the list the next stage consumes
@@ -558,13 +660,21 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.list = c->d_lists[0]; a.list_count = c->d_seg_counts;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = 1;
         a.defer_list = c->d_lists[1]; a.defer_count = c->d_seg_counts + c->seg_alloc; a.out_seg_cap = seg_cap;
-        uint32_t* mode_out = c->d_counters + 5;
-        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
-        else if (d_hash) hipLaunchKernelGGL((canon_rescue_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
-        else hipLaunchKernelGGL((canon_rescue_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
-        CK_HIP(c, hipMemcpyAsync(c->h_mode, mode_out, 4, hipMemcpyDeviceToHost, c->stream));
-        CK_HIP(c, hipEventRecord(c->mode_ev, c->stream));
-        c->mode_pending = true;
+#ifdef CK_NO_PINNED_MODE
+        uint32_t* mode_out = c->d_counters + 6;
+#else
+        uint32_t* mode_out = c->d_mode;               // straight into pinned host memory: no copy-back, no event
+#endif
+        // both alphabets' builds unless the host has decided; the one the mode does not name returns at once
+        const bool lean = !host_mode || !(host_mode & MODE_ALPHA), alpha = !host_mode || (host_mode & MODE_ALPHA);
+        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+        else if (d_hash) {
+            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<true, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<true, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+        } else {
+            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<false, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+        }
     }
     for (int t = 0; t < N_TIERS; ++t) {
         const bool last = t == N_TIERS - 1;
@@ -579,16 +689,17 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.slice_dw = TIER_DW[t];
         // `grid` virtual workgroups; launched: a few times what is resident at once (dispatch order balances the rest)
         const unsigned launched = grid < (unsigned)N_CU * CK_TIER_BPC ? grid : (unsigned)N_CU * CK_TIER_BPC;
-        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid);
-        else hipLaunchKernelGGL(canon_kernel<1>, dim3(launched), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid);
+        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
+        else hipLaunchKernelGGL(canon_kernel<1>, dim3(launched), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, last ? c->d_counters : (uint32_t*)nullptr);
         nseg = grid;
         seg_cap = spb * seg_cap;
     }
     {
         // Records no LDS tier can hold (2-bit beyond ~258 kb, byte-mode beyond ~76 kb): the same code, one wave per
-        // record, with a slice of the global scratch in place of the LDS slice.  Stage 1: up to 64 waves x 4 MiB
-        // (2-bit records up to ~6.7 Mb); stage 2: one wave with the whole scratch (256 MiB by default: 2-bit up to
-        // ~430 Mb, bytes up to ~126 MB; see circkit_ctx_set_long_record_scratch).  Beyond: counted in status[0].
+        // record, with a slice of the global scratch in place of the LDS slice -- one more launch.  Phase 1: up to 64
+        // waves x 4 MiB (2-bit records up to ~6.7 Mb); phase 2 (the last workgroup to finish): one wave with the whole
+        // scratch (256 MiB by default: 2-bit up to ~430 Mb, bytes up to ~126 MB; circkit_ctx_set_long_record_scratch).
+        // Beyond: counted in status[0].
         const uint64_t cap_dw = c->cap_gscratch / 4;
         const uint64_t slice1 = cap_dw < GSLICE1_DW ? cap_dw : GSLICE1_DW;
         const unsigned max_w1 = (unsigned)(cap_dw / slice1 < 64 ? cap_dw / slice1 : 64);
@@ -597,12 +708,12 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb1;
         a.defer_list = c->d_lists[1]; a.defer_count = c->d_seg_counts + c->seg_alloc; a.out_seg_cap = spb1 * seg_cap;
         a.slice_dw = (uint32_t)slice1;
-        hipLaunchKernelGGL(canon_global_kernel, dim3(w1), dim3(64), 0, c->stream, a, c->d_gscratch);
-        a.list = c->d_lists[1]; a.list_count = c->d_seg_counts + c->seg_alloc;
-        a.in_nseg = w1; a.in_seg_cap = spb1 * seg_cap; a.segs_per_block = w1;
-        a.defer_list = nullptr; a.defer_count = nullptr; a.out_seg_cap = 0;
-        a.slice_dw = (uint32_t)(cap_dw < 0xFFFFFFFFull ? cap_dw : 0xFFFFFFFFull);
-        hipLaunchKernelGGL(canon_global_kernel, dim3(1), dim3(64), 0, c->stream, a, c->d_gscratch);
+        ck::CanonArgs a2 = a;
+        a2.list = c->d_lists[1]; a2.list_count = c->d_seg_counts + c->seg_alloc;
+        a2.in_nseg = w1; a2.in_seg_cap = spb1 * seg_cap; a2.segs_per_block = w1;
+        a2.defer_list = nullptr; a2.defer_count = nullptr; a2.out_seg_cap = 0;
+        a2.slice_dw = (uint32_t)(cap_dw < 0xFFFFFFFFull ? cap_dw : 0xFFFFFFFFull);
+        hipLaunchKernelGGL(canon_global_kernel, dim3(w1), dim3(64), 0, c->stream, a, a2, c->d_gscratch, c->d_counters + 2, (const uint32_t*)c->d_counters);
     }
     if (d_hash) {
         hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed);
@@ -623,18 +734,18 @@ int launch_single(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = 1;
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = nullptr; a.hashed = nullptr;
     a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
-    CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    CK_HIP(c, hipMemsetAsync(c->d_counters + 3, 0, sizeof(uint32_t), c->stream));
     const uint64_t need = worst_case_dw(len);
     int t = 0;
     while (t < N_TIERS && TIER_DW[t] < need) ++t;
     if (t < N_TIERS) {
         a.slice_dw = TIER_DW[t];
-        hipLaunchKernelGGL(canon_kernel<1>, dim3(1), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, 1u);
+        hipLaunchKernelGGL(canon_kernel<1>, dim3(1), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, 1u, (uint32_t*)nullptr);
     } else {
         int rc = ensure_gscratch(c, need * 4);
         if (rc) return rc;
         a.slice_dw = (uint32_t)(need < 0xFFFFFFFFull ? need : 0xFFFFFFFFull);
-        hipLaunchKernelGGL(canon_global_kernel, dim3(1), dim3(64), 0, c->stream, a, c->d_gscratch);
+        hipLaunchKernelGGL(canon_global_one_kernel, dim3(1), dim3(64), 0, c->stream, a, c->d_gscratch);
     }
     if (d_hash) hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, d_out, d_offsets, (uint64_t)1, d_hash, (const uint8_t*)nullptr);
     CK_HIP(c, hipGetLastError());
@@ -701,8 +812,17 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     } else {
         // ...and sizes the global scratch for the longest record, whatever mode it turns out to need
         if (worst_case_dw(max_len) > TIER_D_DW && (rc = ensure_gscratch(c, worst_case_dw(max_len) * 4))) return rc;
+        // ...samples the content like stream_count_kernel does (a byte outside ACGT in the first 1008 of a sampled record)
+        const uint64_t nc = n < CONTENT_SAMPLES ? n : CONTENT_SAMPLES, cstep = n / nc;
+        uint64_t bad = 0;
+        for (uint64_t k = 0; k < nc; ++k) {
+            const uint64_t o = offsets[k * cstep], len = offsets[k * cstep + 1] - o, m = len < ck::FAST_MAX_N ? len : ck::FAST_MAX_N;
+            bool b = false;
+            for (uint64_t i = 0; i < m && !b; ++i) { const uint8_t ch = bytes[o + i]; b = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
+            bad += b;
+        }
         rc = launch_canon(c, c->d_in, c->d_off, n, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
-                          strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags, stream_mode(two_word, longer, n));
+                          strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags, stream_mode(two_word, longer, n) | alpha_mode(bad, nc));
     }
     if (rc) return rc;
     if (out && total) CK_HIP(c, hipMemcpyAsync(out, c->d_out, total, hipMemcpyDeviceToHost, c->stream));
@@ -741,12 +861,12 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     c->stream = c->own_stream;
     CK_HIP(c, hipEventCreate(&c->ev0));
     CK_HIP(c, hipEventCreate(&c->ev1));
-    CK_HIP(c, hipEventCreateWithFlags(&c->mode_ev, hipEventDisableTiming));
-    CK_HIP(c, hipHostMalloc((void**)&c->h_mode, 64, hipHostMallocDefault));
+    CK_HIP(c, hipHostMalloc((void**)&c->h_mode, 64, hipHostMallocMapped));
     *c->h_mode = 0;
+    CK_HIP(c, hipHostGetDevicePointer((void**)&c->d_mode, (void*)c->h_mode, 0));
     CK_HIP(c, hipMalloc(&c->d_comp, 256));
-    CK_HIP(c, hipMalloc(&c->d_counters, 8 * sizeof(uint32_t)));
-    CK_HIP(c, hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t)));
+    CK_HIP(c, hipMalloc(&c->d_counters, 16 * sizeof(uint32_t)));
+    CK_HIP(c, hipMemset(c->d_counters, 0, 16 * sizeof(uint32_t)));
     uint8_t comp[256];
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
     // bio 1.3.1 alphabets::dna complement table (call site lib/src/canonicalize.rs:56)
@@ -769,8 +889,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     for (uint32_t* p : c->d_lists) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->mode_ev) (void)hipEventDestroy(c->mode_ev);
-    if (c->h_mode) (void)hipHostFree(c->h_mode);
+    if (c->h_mode) (void)hipHostFree((void*)c->h_mode);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return CIRCKIT_OK;
@@ -836,8 +955,8 @@ int circkit_ctx_last_batch_mode(circkit_ctx* c, uint32_t* mode)
 {
     if (!c || !mode) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
-    CK_HIP(c, hipMemcpyAsync(mode, c->d_counters + 5, 4, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
+    *mode = *c->h_mode & 3;
     return CIRCKIT_OK;
 }
 
@@ -959,8 +1078,7 @@ int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
         if ((rc = grow(c, c->d_table, cap + 1))) return rc;
         c->uniq_mask = cap - 1;
     }
-    hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_table, cap + 1);
-    CK_HIP(c, hipMemsetAsync(c->d_counters + 4, 0, 4, c->stream));
+    hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_table, cap + 1, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     c->uniq_count = 0;
     return CIRCKIT_OK;
@@ -978,7 +1096,7 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
         while (cap < 4 * (c->uniq_count + n)) cap <<= 1;
         UniqSlot* nt = nullptr;
         CK_HIP(c, hipMalloc(&nt, (cap + 1) * sizeof(UniqSlot)));
-        hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nt, cap + 1);
+        hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nt, cap + 1, (uint32_t*)nullptr);
         if (c->d_table) {
             hipLaunchKernelGGL(uniq_rehash_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const UniqSlot*)c->d_table, c->uniq_mask + 2, nt, cap - 1);
             const hipError_t e = hipStreamSynchronize(c->stream);

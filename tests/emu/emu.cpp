@@ -120,7 +120,7 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false; };
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false; };
 void wave_body(void* p)
 {
     Launch* L = (Launch*)p;
@@ -130,9 +130,9 @@ void rescue_body(void* p)
 {
     Launch* L = (Launch*)p;
     const bool aux = L->a.out_index || L->a.out_strand || (L->a.flags & ck::CK_FLAG_FWD_ONLY);
-    if (aux) { ck::RescueState<true, true> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, true>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
-    else if (L->a.out_hash) { ck::RescueState<true, false> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
-    else { ck::RescueState<false, false> st; ck::canon_rescue_segment<false, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
+    if (aux) { ck::RescueState<true, true> st; st.hc = ck::fast_hash_const(); ck::canon_rescue_segment<true, true, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
+    else if (L->a.out_hash) { ck::RescueState<true, false> st; st.hc = ck::fast_hash_const(); if (L->alpha) ck::canon_rescue_segment<true, false, true>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); else ck::canon_rescue_segment<true, false, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
+    else { ck::RescueState<false, false> st; if (L->alpha) ck::canon_rescue_segment<false, false, true>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); else ck::canon_rescue_segment<false, false, false>(L->a, L->lut, st, L->blk_count, L->block, L->wib, 4, L->all_records); }
 }
 template <class C>
 void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
@@ -174,7 +174,7 @@ void hash_body(void* q)
 extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
                                       uint8_t* out_bytes, uint32_t* out_index, uint8_t* out_strand,
                                       uint64_t* out_hash, uint32_t slice_dw, uint32_t n_waves,
-                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast, uint32_t* n_fused_hash, int staged, uint32_t* n_rescued)
+                                      uint32_t* n_deferred, uint32_t flags, uint32_t* n_fast, uint32_t* n_fused_hash, int staged, uint32_t* n_rescued, int alpha)
 {
     uint8_t comp[256];
     for (int v = 0; v < 256; ++v) comp[v] = (uint8_t)v;
@@ -211,6 +211,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     }
     if (all_records) total_f = (uint32_t)n_records;
     L.all_records = all_records;
+    L.alpha = alpha != 0;        // which build of the rescue pass (launch_canon: MODE_ALPHA of the batch's mode)
     if (n_fast) *n_fast = (uint32_t)n_records - total_f;
     // rescue pass: the streaming kernel's leftovers that are eligible by themselves (same build choice as launch_canon)
     std::vector<uint32_t> list_r((size_t)G * cap), cnt_r(G, 0);

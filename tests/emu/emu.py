@@ -30,16 +30,35 @@ STAGED_GEOMETRIES = {1: (16, 1, 2), 2: (8, 2, 3), 3: (4, 2, 2), 4: (8, 2, 2), 5:
 TWO_ROW = (10, 11, 12)
 
 
+def alpha_rule(data, offsets):
+    """launch_canon's content rule (MODE_ALPHA): of up to 4096 evenly spaced records, one in 16 or more holds a byte
+    outside ACGT among its first 1008."""
+    n = len(offsets) - 1
+    if n == 0:
+        return False
+    nc = min(n, 4096)
+    step = n // nc
+    ok = np.zeros(256, dtype=bool)
+    ok[list(b"ACGT")] = True
+    bad = 0
+    for k in range(nc):
+        a, b = int(offsets[k * step]), int(offsets[k * step + 1])
+        bad += not ok[data[a:min(b, a + 1008)]].all()
+    return bad > 0 and bad * 16 >= nc
+
+
 def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1, want_aux=True,
-                       base_shift=0, lead=0):
+                       base_shift=0, lead=0, alpha=None):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
         _lib.emu_canonicalize_batch.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_uint64] + [ctypes.c_void_p] * 4 + \
-            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+            [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
+    if alpha is None:
+        alpha = alpha_rule(data, offsets)
     # base_shift: misalignment of the payload pointer; lead: offsets[0] (canary bytes in front of the first record)
     assert offsets[0] == 0
     offsets = offsets + np.uint64(lead)
@@ -60,7 +79,7 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data,
                                      idx.ctypes.data if want_aux else None, strand.ctypes.data if want_aux else None,
                                      hs.ctypes.data if want_hash else None,
-                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged), ctypes.byref(nresc))
+                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged), ctypes.byref(nresc), int(bool(alpha)))
     assert st >= 0, "emulator rejected the launch (unknown `staged` geometry?)"
     global last_fast_count, last_fused_hash_count, last_rescued_count
     last_rescued_count = nresc.value

@@ -192,7 +192,7 @@ def test_rescue_pass_takes_short_records_of_unstaged_groups():
     want = [seqsets.expected(O, s) for s in seqs]
     for want_hash, want_aux in ((False, False), (True, False), (True, True)):
         out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=want_hash, want_aux=want_aux, staged=1,
-                                                                   slice_dw=8192, n_waves=24)
+                                                                   slice_dw=8192, n_waves=24, alpha=True)
         assert emu.last_fast_count == 0                                  # no group could be staged
         assert emu.last_rescued_count == 6 * 15 + (0 if want_aux else 5)
         for i, s in enumerate(seqs):
@@ -245,7 +245,7 @@ def test_four_bit_register_path_takes_n_and_gap_records():
     want = [seqsets.expected(O, s) for s in seqs]
     for staged, want_hash in ((0, False), (0, True), (1, False)):
         out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=want_hash, want_aux=False, staged=staged,
-                                                                   slice_dw=4096, n_waves=12)
+                                                                   slice_dw=4096, n_waves=12)     # alpha: decided by the content rule
         assert emu.last_rescued_count >= len(seqs) - 12                  # all but periodic records / ties on the 8-symbol key
         for i, s in enumerate(seqs):
             a, b = int(offs[i]), int(offs[i + 1])

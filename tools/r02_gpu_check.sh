@@ -11,3 +11,5 @@ tail -25 gpurun_out/r02_pytest.log
 python bench.py > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err && cat gpurun_out/r02_bench.json &&
 python bench.py --workload uniq > gpurun_out/r02_bench_uniq.json 2> gpurun_out/r02_bench_uniq.err && cat gpurun_out/r02_bench_uniq.json &&
 python bench.py --workload mixed > gpurun_out/r02_bench_mixed.json 2> gpurun_out/r02_bench_mixed.err && cat gpurun_out/r02_bench_mixed.json
+python bench.py --n-frac 0.01 > gpurun_out/r02_bench_n1pct.json 2> gpurun_out/r02_bench_n1pct.err && cat gpurun_out/r02_bench_n1pct.json &&
+python bench.py --workload mixed --n-frac 0.01 > gpurun_out/r02_bench_mixed_n1pct.json 2> gpurun_out/r02_bench_mixed_n1pct.err && cat gpurun_out/r02_bench_mixed_n1pct.json
