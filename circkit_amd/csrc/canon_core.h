@@ -70,6 +70,34 @@ CK_DEV uint32_t sym_word(const uint32_t* E, uint32_t p, uint32_t n)
     return funnel(E[w], E[w + 1], sh);
 }
 
+// reverse complement of one packed word: symbol order reversed, every symbol complemented
+template <int BITS>
+CK_DEV uint32_t rc_word(uint32_t g)
+{
+    if (BITS == 2) {
+        const uint32_t v = bitrev(~g);                      // reverses bits; swap the two bits of every symbol back
+        return bfi(0x55555555u, v >> 1, v << 1);
+    }
+    // 4-bit codes '-'0 A1 C2 G3 N4 T5: complement by v_perm as an 8-entry table (0 5 3 2 4 1), the nibbles of a byte
+    // swapped while they are apart, then the bytes reversed
+    const uint32_t lo = perm(0x00000104u, 0x02030500u, g & 0x0F0F0F0Fu), hi = perm(0x00000104u, 0x02030500u, (g >> 4) & 0x0F0F0F0Fu);
+    return perm(0u, (lo << 4) | hi, 0x00010203u);
+}
+
+// A strand as the LDS tiers see it: packed words in E, or -- RCV, 2-bit records only -- the reverse complement of the
+// strand in E without a copy of its own: the S symbols at position p of rc(s) are the complement, in reverse order, of
+// the forward symbols [n - S - p, n - p) (mod n), so a view costs one forward window + rc_word().  Not keeping the
+// second strand halves the LDS a 2-bit record needs, i.e. doubles the records (waves) a CU holds in the one-wave tiers.
+template <int BITS, bool RCV>
+CK_DEV uint32_t view_word(const uint32_t* E, uint32_t p, uint32_t n)     // p < 2n
+{
+    if (!RCV) return sym_word<BITS>(E, p, n);
+    constexpr uint32_t S = 32 / BITS;
+    p = p >= n ? p - n : p;
+    const int32_t s0 = (int32_t)n - (int32_t)S - (int32_t)p;
+    return rc_word<BITS>(sym_word<BITS>(E, (uint32_t)(s0 + ((s0 >> 31) & (int32_t)n)), n));
+}
+
 // min over the S keys that start inside word `cur` (next word `nxt`)
 template <int BITS>
 CK_DEV uint32_t word_min_key(uint32_t cur, uint32_t nxt)
@@ -164,7 +192,7 @@ template <int BITS>
 CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Er)
 {
     constexpr uint32_t S = 32 / BITS;           // bytes consumed per packed word
-    constexpr bool RC_FROM_FWD = BITS == 2;     // 2-bit complement is `~`: the reverse strand comes from Ef, not from memory
+    constexpr bool RC_FROM_FWD = BITS == 2;     // 2-bit: the reverse strand is a VIEW of Ef (view_word), never stored
     const uint32_t lane = lane_id();
     const uint32_t nwf = n / S, r = n % S, nwv = nwf + (r ? 1u : 0u);
     uint32_t bad = 0;
@@ -172,7 +200,8 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
     // first is consumed: a long record is otherwise one exposed HBM round trip per row (measured: tier B of
     // BASELINE config 4 spent 61 % of its wave cycles in s_waitcnt with the VALU 20 % busy).
     constexpr int U = CK_BUILD_ROWS;
-    for (uint32_t w0 = lane; w0 < nwv; w0 += 64 * U) {
+    for (uint32_t base = 0; base < nwv; base += 64 * U) {          // wave-uniform trip count (the early exit below is a collective)
+        const uint32_t w0 = base + lane;
         u32x4 vf[U], vc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -205,6 +234,8 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
                 }
             }
         }
+        // a byte outside the alphabet: no point in packing the rest (with 1 % N the first rows of a long record show it)
+        if (ballot(bad != 0) != 0) break;
     }
     const bool ok = ballot(bad != 0) == 0;
     wave_sync();
@@ -222,18 +253,6 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
         }
     }
     wave_sync();
-    if (RC_FROM_FWD && ok) {
-        // reverse strand, extension words included: word w = comp(reverse(forward symbols [n - 16(w+1), n - 16w)
-        // mod n)); the window may run past the record end into Ef's extension, never past it (n >= 48)
-        for (uint32_t w = lane; w < nwv + 2; w += 64) {
-            const int32_t p0 = (int32_t)n - 16 * (int32_t)(w + 1);
-            const uint32_t p = (uint32_t)(p0 + ((p0 >> 31) & (int32_t)n));
-            const uint32_t g = ~funnel(Ef[p >> 4], Ef[(p >> 4) + 1], (p & 15) * 2);
-            const uint32_t v = bitrev(g);                   // reverses bits; swap the two bits of every symbol back
-            Er[w] = bfi(0x55555555u, v >> 1, v << 1);
-        }
-        wave_sync();
-    }
     return ok;
 }
 
@@ -258,7 +277,7 @@ CK_DEV void build_bytes(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* 
 // ------------------------------------------------------------------------------------------------
 // wave-parallel longest common prefix of rotation i of A and rotation j of B (both length n)
 // ------------------------------------------------------------------------------------------------
-template <int BITS>
+template <int BITS, bool RA, bool RB>
 CK_DEV Lcp lcp_rot(const uint32_t* A, const uint32_t* B, uint32_t i, uint32_t j, uint32_t n)
 {
     constexpr uint32_t S = 32 / BITS;
@@ -267,8 +286,8 @@ CK_DEV Lcp lcp_rot(const uint32_t* A, const uint32_t* B, uint32_t i, uint32_t j,
         const uint32_t off = base + lane * S;
         uint32_t a = 0, b = 0;
         if (off < n) {
-            a = sym_word<BITS>(A, i + off, n);
-            b = sym_word<BITS>(B, j + off, n);
+            a = view_word<BITS, RA>(A, i + off, n);
+            b = view_word<BITS, RB>(B, j + off, n);
         }
         const uint32_t d = a ^ b;
         const uint64_t bal = ballot(d != 0);
@@ -304,19 +323,28 @@ CK_DEV uint32_t next_cand(const uint32_t* bm, uint32_t x, uint32_t n)
 // ------------------------------------------------------------------------------------------------
 // smallest index of the lexicographically minimal rotation + the rotation period
 // ------------------------------------------------------------------------------------------------
-template <int BITS>
+template <int BITS, bool RCV>
 CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
 {
     constexpr uint32_t S = 32 / BITS;
     const uint32_t lane = lane_id();
     const uint32_t nwv = (n + S - 1) / S;
 
-    // dense scan: per-lane minimum key, which word owns it, and how many of the lane's words tie
+    // dense scan: per-lane minimum key, which word owns it, and how many of the lane's words tie.  Every word is
+    // fetched once: the word behind it is the next lane's (DPP), lane 63's the first word of the next row.
     uint32_t best = ~0u, bestw = 0, ties = 0;
-    for (uint32_t w = lane; w < nwv; w += 64) {
-        const uint32_t m = word_min_key<BITS>(E[w], E[w + 1]);
-        if (m < best || ties == 0) { best = m; bestw = w; ties = 1; }
-        else if (m == best) ++ties;
+    uint32_t cur = lane < nwv + 1 ? view_word<BITS, RCV>(E, lane * S, n) : 0u;
+    for (uint32_t w0 = 0; w0 < nwv; w0 += 64) {
+        const uint32_t w = w0 + lane;
+        const uint32_t ahead = w + 64 < nwv + 1 ? view_word<BITS, RCV>(E, (w + 64) * S, n) : 0u;     // this lane's word of the next row
+        const uint32_t first_of_next_row = readlane(ahead, 0), neighbour = wave_shl1(cur);      // (collectives: every lane, unconditionally)
+        const uint32_t nxt = lane == 63 ? first_of_next_row : neighbour;
+        if (w < nwv) {
+            const uint32_t m = word_min_key<BITS>(cur, nxt);
+            if (m < best || ties == 0) { best = m; bestw = w; ties = 1; }
+            else if (m == best) ++ties;
+        }
+        cur = ahead;
     }
     const uint32_t M = wave_min_u32(best);
     const uint64_t hm = ballot(ties != 0 && best == M);
@@ -333,7 +361,7 @@ CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
             const uint32_t tl = readlane(ties, l), wl = readlane(bestw, l);
             if (tl != 1) { multi = true; break; }
             const uint32_t b = lane % S;
-            const uint32_t k = funnel(E[wl], E[wl + 1], b * BITS);
+            const uint32_t k = view_word<BITS, RCV>(E, wl * S + b, n);
             const uint64_t pm = ballot(lane < S && k == M && wl * S + b < n);
             cnt += (uint32_t)popc64(pm);
             if (pm) pos = wl * S + (uint32_t)ffs64(pm);
@@ -346,15 +374,11 @@ CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
     for (uint32_t t = lane; t < nbm; t += 64) bm[t] = 0;
     wave_sync();
     for (uint32_t w = lane; w < nwv; w += 64) {
-        uint32_t m = word_eq_mask<BITS>(E[w], E[w + 1], M);
+        uint32_t m = word_eq_mask<BITS>(view_word<BITS, RCV>(E, w * S, n), view_word<BITS, RCV>(E, (w + 1) * S, n), M);
         const uint32_t valid = n - w * S;
         if (valid < S) m &= (1u << valid) - 1u;
         const uint32_t p = w * S;
-#ifndef CK_EMU
-        if (m) atomicOr(&bm[p / 32], m << (p % 32));
-#else
-        if (m) bm[p / 32] |= m << (p % 32);
-#endif
+        if (m) lds_atomic_or(&bm[p / 32], m << (p % 32));
     }
     wave_sync();
     // 2: duel.  Invariant: alive candidates = {i} U {candidates >= j}; a minimal start is never killed.
@@ -362,7 +386,7 @@ CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
     uint32_t j = next_cand(bm, i + 1, n);
     uint32_t period = n;
     while (j < n) {
-        const Lcp c = lcp_rot<BITS>(E, E, i, j, n);
+        const Lcp c = lcp_rot<BITS, RCV, RCV>(E, E, i, j, n);
         if (c.k >= n) { period = j - i; break; }       // equal rotations: i is the smallest minimal start
         if (c.cmp > 0) {                                // rotation j is smaller: i .. i+k are dead
             const uint32_t ni = (i + c.k + 1 <= j) ? j : next_cand(bm, i + c.k + 1, n);
@@ -412,22 +436,30 @@ CK_DEV void decode4(uint32_t v, uint32_t& lo, uint32_t& hi)
 }
 
 // lut: the 256-entry packed-byte -> 4 ASCII bytes table of fast_lut_init() in LDS (2-bit mode), or nullptr
-template <int BITS>
+template <int BITS, bool RCV>
+CK_DEV u32x4 decode_word(const uint32_t* E, uint32_t p, uint32_t n, const uint32_t* lut)      // the S symbols at position p as ASCII
+{
+    const uint32_t v = view_word<BITS, RCV>(E, p, n);
+    u32x4 o{ 0, 0, 0, 0 };
+    if (BITS == 2) {
+        o = lut ? fast_decode(lut, v) : decode2(v);
+    } else if (BITS == 4) {
+        decode4(v, o.x, o.y);
+    } else {
+        o.x = perm(0u, v, 0x00010203u);
+    }
+    return o;
+}
+// (Cutting the output at the 16-byte boundaries of the destination -- aligned dwordx4 stores -- and building the 2-bit
+// strand from aligned loads + a funnel on the packed words were both tried on BASELINE config 4: 2.39 -> 2.8 ms.)
+template <int BITS, bool RCV>
 CK_DEV void emit(const uint32_t* E, uint32_t idx, uint32_t n, uint8_t* out, const uint32_t* lut)
 {
     constexpr uint32_t S = 32 / BITS;
     const uint32_t nwv = (n + S - 1) / S;
     for (uint32_t w = lane_id(); w < nwv; w += 64) {
-        const uint32_t v = sym_word<BITS>(E, idx + w * S, n);
+        const u32x4 o = decode_word<BITS, RCV>(E, idx + w * S, n, lut);
         const uint32_t left = n - w * S;
-        u32x4 o{ 0, 0, 0, 0 };
-        if (BITS == 2) {
-            o = lut ? fast_decode(lut, v) : decode2(v);
-        } else if (BITS == 4) {
-            decode4(v, o.x, o.y);
-        } else {
-            o.x = perm(0u, v, 0x00010203u);
-        }
         store_bytes(out + w * S, o, left < S ? left : S);
     }
 }
@@ -439,7 +471,7 @@ template <int BITS>
 CK_DEV uint32_t need_dw(uint32_t n)
 {
     constexpr uint32_t S = 32 / BITS;
-    return 2 * ((n + S - 1) / S + 2) + (n + 31) / 32 + 1;
+    return (BITS == 2 ? 1 : 2) * ((n + S - 1) / S + 2) + (n + 31) / 32 + 1;      // one stored strand in 2-bit mode, two otherwise
 }
 
 template <int BITS>
@@ -447,24 +479,28 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
                               uint32_t* lds, const uint32_t* lut)
 {
     constexpr uint32_t S = 32 / BITS;
+    constexpr bool RCV = BITS == 2;              // reverse strand = a view of the forward words
     const uint32_t nwv = (n + S - 1) / S;
     uint32_t* Ef = lds;
-    uint32_t* Er = lds + (nwv + 2);
-    uint32_t* bm = lds + 2 * (nwv + 2);
+    uint32_t* Er = RCV ? lds : lds + (nwv + 2);
+    uint32_t* bm = lds + (RCV ? 1 : 2) * (nwv + 2);
     if (BITS == 8) {
         build_bytes(src, n, Ef, Er, a.comp_lut);
     } else {
         if (!build_packed<BITS>(src, n, Ef, Er)) return false;
     }
-    const RotResult f = find_min_rot<BITS>(Ef, n, bm);
+    const RotResult f = find_min_rot<BITS, false>(Ef, n, bm);
     RotResult r{ 0, n };
     bool fwd = true;
     if (!(a.flags & CK_FLAG_FWD_ONLY)) {
-        r = find_min_rot<BITS>(Er, n, bm);
+        r = find_min_rot<BITS, RCV>(Er, n, bm);
         // lib/src/canonicalize.rs:58-62: forward only if strictly smaller
-        fwd = lcp_rot<BITS>(Ef, Er, f.idx, r.idx, n).cmp < 0;
+        fwd = lcp_rot<BITS, false, RCV>(Ef, Er, f.idx, r.idx, n).cmp < 0;
     }
-    if (a.out_bytes) emit<BITS>(fwd ? Ef : Er, fwd ? f.idx : r.idx, n, a.out_bytes + off, lut);
+    if (a.out_bytes) {
+        if (fwd) emit<BITS, false>(Ef, f.idx, n, a.out_bytes + off, lut);
+        else emit<BITS, RCV>(Er, r.idx, n, a.out_bytes + off, lut);
+    }
     if (lane_id() == 0) {
         // index as the reference would see it: lmsr_index(s) for the forward strand,
         // lmsr_index(revcomp(lmsr(s))) for the reverse strand (rotation by f.idx, modulo the period)
@@ -475,8 +511,12 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
 }
 
 
-// Processes one record; returns false if it does not fit this tier's LDS slice.
-CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut)
+// List entries: bits 0..30 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
+// that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte).
+constexpr uint32_t ENTRY_NOT_ACGT = 0x80000000u, ENTRY_REC = 0x7FFFFFFFu;
+
+// Processes one record; returns false if it does not fit this tier's LDS slice (not_acgt then says what was learnt).
+CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, bool& not_acgt)
 {
     const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
     if (len >> 31) return false;                 // 32-bit cyclic positions (p < 2n): a record of 2 Gi symbols or more fits nowhere
@@ -490,8 +530,11 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
         return true;
     }
     if (n >= 48) {
-        if (need_dw<2>(n) > a.slice_dw) return false;
-        if (canon_record_mode<2>(a, rec, src, off, n, lds, lut)) return true;
+        if (!not_acgt) {
+            if (need_dw<2>(n) > a.slice_dw) return false;
+            if (canon_record_mode<2>(a, rec, src, off, n, lds, lut)) return true;
+            not_acgt = true;
+        }
         if (need_dw<4>(n) > a.slice_dw) return false;
         if (canon_record_mode<4>(a, rec, src, off, n, lds, lut)) return true;
     }
@@ -501,10 +544,10 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
 }
 
 // append a record this launch cannot take to the workgroup's output segment (blk_count lives in LDS)
-CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block, uint32_t rec)
+CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block, uint32_t rec, bool not_acgt = false)
 {
     if (lane_id() == 0) {
-        if (a.defer_list) a.defer_list[(uint64_t)block * a.out_seg_cap + lds_atomic_inc(blk_count)] = rec;
+        if (a.defer_list) a.defer_list[(uint64_t)block * a.out_seg_cap + lds_atomic_inc(blk_count)] = rec | (not_acgt ? ENTRY_NOT_ACGT : 0u);
         else atomic_add_u32(a.status, 1u);
     }
 }
@@ -516,7 +559,8 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
 {
     if (!a.list) {
         for (uint64_t rec = (uint64_t)block * wpb + wib; rec < a.n_records; rec += (uint64_t)nblocks * wpb) {
-            if (!canon_record(a, rec, lds, lut)) defer_record(a, blk_count, block, (uint32_t)rec);
+            bool not_acgt = false;
+            if (!canon_record(a, rec, lds, lut, not_acgt)) defer_record(a, blk_count, block, (uint32_t)rec, not_acgt);
             wave_sync();
         }
         return;
@@ -525,8 +569,9 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
         const uint32_t count = a.list_count[s];
         const uint32_t* seg = a.list + (uint64_t)s * a.in_seg_cap;
         for (uint32_t i = wib; i < count; i += wpb) {
-            const uint32_t rec = seg[i];
-            if (!canon_record(a, rec, lds, lut)) defer_record(a, blk_count, block, rec);
+            const uint32_t rec = seg[i] & ENTRY_REC;
+            bool not_acgt = (seg[i] & ENTRY_NOT_ACGT) != 0;
+            if (!canon_record(a, rec, lds, lut, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
             wave_sync();
         }
     }

@@ -340,20 +340,6 @@ CK_DEV uint32_t fast2x_locate(uint32_t E0, uint32_t E1, uint32_t E0n, uint64_t h
     return pos;
 }
 
-// reverse complement of one packed word: symbol order reversed, every symbol complemented
-template <int BITS>
-CK_DEV uint32_t rc_word(uint32_t g)
-{
-    if (BITS == 2) {
-        const uint32_t v = bitrev(~g);                      // reverses bits; swap the two bits of every symbol back
-        return bfi(0x55555555u, v >> 1, v << 1);
-    }
-    // 4-bit codes '-'0 A1 C2 G3 N4 T5: complement by v_perm as an 8-entry table (0 5 3 2 4 1), the nibbles of a byte
-    // swapped while they are apart, then the bytes reversed
-    const uint32_t lo = perm(0x00000104u, 0x02030500u, g & 0x0F0F0F0Fu), hi = perm(0x00000104u, 0x02030500u, (g >> 4) & 0x0F0F0F0Fu);
-    return perm(0u, (lo << 4) | hi, 0x00010203u);
-}
-
 // XXH3-64 of a two-words-per-lane record (1009..2032 bytes: one or two 1024-byte blocks), fused like fast_hash: per
 // block the lanes re-fetch the canonical bytes in the hash's own layout (lane t = cell (stripe t>>2, pair t&3) of the
 // block), accumulate, sum over the stripes, and the first block is followed by XXH3's scramble; last stripe, merge and

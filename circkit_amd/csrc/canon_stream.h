@@ -159,7 +159,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 const uint64_t bad = ballot(miss != 0) & (~0ull >> (64 - nch));         // 3 <= nch <= 64
                 done = fast_canon<HASH, AUX>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
             }
-            if (!done) defer_record(a, blk_count, block, rec);
+            if (!done) defer_record(a, blk_count, block, rec);       // (no alphabet flag: the edge chunks hold neighbours' bytes too)
         }
         // the previous group's hashes: its slots were complete at the barrier that ended the previous iteration
         if constexpr (GH) {
@@ -214,7 +214,7 @@ CK_DEV RescueMeta rescue_meta(const CanonArgs& a, const uint32_t* seg, uint64_t 
     const uint32_t t = lane_id();
     RescueMeta m{ 0, 0, 0 };
     if (t < RESCUE_CHUNK && c0 + t < count) {
-        m.rec = all_records ? (uint32_t)first + c0 + t : seg[c0 + t];
+        m.rec = all_records ? (uint32_t)first + c0 + t : seg[c0 + t] & ENTRY_REC;
         m.off = a.offsets[m.rec];
         const uint64_t len = a.offsets[m.rec + 1] - m.off;
         m.len = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
@@ -237,13 +237,14 @@ CK_DEV void rescue_one(const CanonArgs& a, const uint32_t* lut, RescueState<HASH
     const uint32_t t = lane_id();
     const uint32_t rec = readlane(cur.rec, l), n = readlane(cur.len, l);
     const uint64_t off = ((uint64_t)readlane((uint32_t)(cur.off >> 32), l) << 32) | readlane((uint32_t)cur.off, l);
-    bool done = false;
+    bool done = false, not_acgt = false;
     if (fast_eligible(n)) {
         const uint32_t nwf = n >> 4;
         const uint32_t tail_syms = t >= nwf ? (16 - (n & 15)) & 15 : 0;       // the tail lane's symbols move up by this much
         uint32_t miss;
         const uint32_t F = fast_pack(v, miss);
         const uint64_t bad = ballot(miss != 0);
+        not_acgt = bad != 0;                              // (exact here: the lanes hold this record's bytes only)
         if (AUX || bad == 0) {
             done = fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F << (2 * tail_syms), bad);
         } else {
@@ -255,7 +256,7 @@ CK_DEV void rescue_one(const CanonArgs& a, const uint32_t* lut, RescueState<HASH
             done = fast_canonw<4, HASH, false>(a, lut, st.hc, rec, off, n, (uint32_t)(x >> 32), (uint32_t)x, ballot(bad4 != 0) != 0);
         }
     }
-    if (!done) defer_record(a, seg_count, seg_index, rec);
+    if (!done) defer_record(a, seg_count, seg_index, rec, not_acgt);
 }
 template <bool HASH, bool AUX, bool ALPHA>
 CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, RescueState<HASH, AUX>& st, uint32_t* seg_count, uint32_t seg_index,
@@ -270,17 +271,19 @@ CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, Rescue
         // the lean build: one record at a time, pure-ACGT records only (what is left after the streaming kernel of an
         // ordinary batch is a handful of records per segment; prefetching bought nothing there, measured)
         for (uint32_t i = wib; i < count; i += wpb) {
-            const uint32_t rec = all_records ? (uint32_t)first + i : seg[i];
+            const uint32_t rec = all_records ? (uint32_t)first + i : seg[i] & ENTRY_REC;
             const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
-            bool done = false;
+            bool done = false, not_acgt = false;
             if (len <= FAST_MAX_N && fast_eligible((uint32_t)len)) {
                 const uint32_t n = (uint32_t)len, nwf = n >> 4;
                 uint32_t miss;
                 uint32_t F = fast_pack(load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t)), miss);
                 F <<= t >= nwf ? ((16 - (n & 15)) & 15) * 2 : 0;
-                done = fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F, ballot(miss != 0));
+                const uint64_t bad = ballot(miss != 0);
+                not_acgt = bad != 0;
+                done = fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F, bad);
             }
-            if (!done) defer_record(a, seg_count, seg_index, rec);
+            if (!done) defer_record(a, seg_count, seg_index, rec, not_acgt);
         }
         return;
     }

@@ -456,16 +456,17 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #ifndef CK_TIER_KEEP
 #define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
 #endif
+#ifndef CK_TIER_A
+#define CK_TIER_A 1023
+#endif
 #ifndef CK_TIER_B1
 #define CK_TIER_B1 2300
 #endif
-#if CK_TIER_B1 > 0
-constexpr int N_TIERS = 5;
-constexpr uint32_t TIER_DW[N_TIERS] = { 1023, CK_TIER_B1, 3324, 9980, 40444 };     // + 260 dwords of counter and decode table per workgroup
-#else
-constexpr int N_TIERS = 4;
-constexpr uint32_t TIER_DW[N_TIERS] = { 1023, 3324, 9980, 40444 };
+#ifndef CK_TIER_B2
+#define CK_TIER_B2 3324
 #endif
+constexpr int N_TIERS = 5;
+constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, 40444 };     // + 260 dwords of counter and decode table per workgroup
 constexpr uint32_t TIER_EXTRA_DW = 4 + 256;
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
 constexpr int N_CU = 256;

@@ -210,6 +210,7 @@ CK_DEV uint32_t load4(const uint8_t* p)
 }
 CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 CK_DEV uint32_t lds_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }     // p in LDS: ds_add_rtn_u32
+CK_DEV void lds_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 
 // Two consecutive u64 (a CSR offset pair) through the scalar cache: s_load_dwordx4, tracked by lgkmcnt, so
 // it never forces a vmcnt(0) that would drain the prefetched record bytes.  The wait is INSIDE the same asm
@@ -424,6 +425,7 @@ CK_DEV void store4(uint8_t* p, uint32_t a) { memcpy(p, &a, 4); }
 CK_DEV uint32_t load4(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 CK_DEV uint32_t lds_atomic_inc(uint32_t* p) { return (*p)++; }
+CK_DEV void lds_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
 struct ck_u32x4v { uint32_t x, y, z, w; };
 CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), gsrc, 16); }
 CK_DEV void glds16_async_s(uint32_t* lds_dst, const uint8_t* sbase, uint32_t voff) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), sbase + voff, 16); }

@@ -223,10 +223,10 @@ def test_long_record_scratch_limit_is_reported(O):
     import circkit_amd
     from tests import seqsets
     c = circkit_amd.Context(0)
-    c.set_long_record_scratch(1 << 20)               # 1 MiB: pure-ACGT records up to ~1.6 Mb
+    c.set_long_record_scratch(1 << 20)               # 1 MiB: pure-ACGT records up to ~2.7 Mb
     rng = np.random.default_rng(6)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    seqs = seqsets.random_mixed(87, 20, 100, 1008) + [acgt[rng.integers(0, 4, 1_000_000)].tobytes(), acgt[rng.integers(0, 4, 2_500_000)].tobytes()]
+    seqs = seqsets.random_mixed(87, 20, 100, 1008) + [acgt[rng.integers(0, 4, 1_000_000)].tobytes(), acgt[rng.integers(0, 4, 3_500_000)].tobytes()]
     data, offs = seqsets.pack(seqs)
     dev = torch.device("cuda", 0)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
