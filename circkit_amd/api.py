@@ -47,6 +47,7 @@ SIGNATURES = {
     "circkit_uniq_insert_pairs_device": (_i, [_vp, _vp, _vp, _u64]),
     "circkit_uniq_lookup_device": (_i, [_vp, _vp, _u64, _vp]),
     "circkit_uniq_status": (_i, [_vp, ctypes.POINTER(_u32)]),
+    "circkit_uniq_resolve_device": (_i, [_vp, _vp, _u64, _u64, _vp, _vp]),
     "circkit_uniq_first_seen": (_i, [_vp, _vp, _u64, _u64, _vp]),
     "circkit_fasta_parse": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(_vp), ctypes.POINTER(_sz)]),
     "circkit_fasta_error": (ctypes.c_char_p, [_vp]),
@@ -197,6 +198,9 @@ class Context:
 
     def uniq_lookup_device(self, d_hash, n, d_first_seen):
         self._check(self._lib.circkit_uniq_lookup_device(self._h, _ptr(d_hash), int(n), _ptr(d_first_seen)))
+
+    def uniq_resolve_device(self, d_hash, n, base_index, d_first_seen, d_keep=None):
+        self._check(self._lib.circkit_uniq_resolve_device(self._h, _ptr(d_hash), int(n), int(base_index), _ptr(d_first_seen), _ptr(d_keep)))
 
     def uniq_status(self):
         """Waits for the queued table work; raises CirckitError (OOM) if keys found no slot."""

@@ -152,18 +152,28 @@ CK_DEV uint32_t fast_pack(u32x4 v, uint32_t& miss)
 
 // 256-entry LDS table: packed byte (4 symbols, first in the top bits) -> its 4 ASCII bytes.  Replaces ~6 VALU
 // per output dword (spread the 2-bit fields into bytes, v_perm) by shift + mask + one ds_read_b32.
+// CK_LUT_STRIDE = 32 (experiment): 32 copies of the table, entry x of copy c at [32 x + c], each lane reads copy
+// lane & 31 -- a wave's data-dependent ds_read_b32 then hits 32 different banks per half by construction (one copy: the
+// 64 random entries collide, SQ_LDS_BANK_CONFLICT ~20 cycles per record in the headline kernel).
+#ifndef CK_LUT_STRIDE
+#define CK_LUT_STRIDE 1
+#endif
+constexpr uint32_t FAST_LUT_DW = 256 * CK_LUT_STRIDE;
 CK_DEV void fast_lut_init(uint32_t* lut, uint32_t tid, uint32_t nthreads)
 {
-    for (uint32_t x = tid; x < 256; x += nthreads) {
+    for (uint32_t i = tid; i < FAST_LUT_DW; i += nthreads) {
+        const uint32_t x = i / CK_LUT_STRIDE;
         uint32_t o = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) o |= ((0x54474341u >> (8 * ((x >> (6 - 2 * k)) & 3))) & 0xFFu) << (8 * k);
-        lut[x] = o;
+        lut[i] = o;
     }
 }
 CK_DEV u32x4 fast_decode(const uint32_t* lut, uint32_t w)
 {
-    return u32x4{ lut[w >> 24], lut[(w >> 16) & 0xFF], lut[(w >> 8) & 0xFF], lut[w & 0xFF] };
+    if (CK_LUT_STRIDE == 1) return u32x4{ lut[w >> 24], lut[(w >> 16) & 0xFF], lut[(w >> 8) & 0xFF], lut[w & 0xFF] };
+    const uint32_t* l = lut + (lane_id() & (CK_LUT_STRIDE - 1));
+    return u32x4{ l[(w >> 24) * CK_LUT_STRIDE], l[((w >> 16) & 0xFF) * CK_LUT_STRIDE], l[((w >> 8) & 0xFF) * CK_LUT_STRIDE], l[(w & 0xFF) * CK_LUT_STRIDE] };
 }
 
 // 4-bit codes: '-'0 A1 C2 G3 N4 T5.  8 bytes (two dwords) per packed word.

@@ -33,7 +33,7 @@ struct StreamCfg {
     // ring, then the decode table, the deferral counter and (ROWS == 2) 1 KiB of padding: a record's lanes past its
     // end read up to 63 / 127 chunks beyond the image (never used), which for the last buffer lands in the table and
     // the padding
-    static constexpr uint32_t LDS_DW = NBUF * BUF_DW + 256 + 4 + (ROWS == 2 ? 256 : 0);
+    static constexpr uint32_t LDS_DW = NBUF * BUF_DW + FAST_LUT_DW + 4 + (ROWS == 2 ? 256 : 0);
 };
 
 // 1 KiB slot of the image that DMA instruction i of wave w fills: the first RPW instructions of every wave tile the

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32
 __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::CanonArgs a2, uint32_t* scratch, uint32_t* ticket, const uint32_t* giants)
 {
     if (*giants == 0) return;           // nothing came out of the last LDS tier (every ordinary batch): the launch costs ~3 us, not ~12
-    __shared__ uint32_t blk_count, lut[256], last;
+    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], last;
     ck::fast_lut_init(lut, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::C
 // one record in global scratch (the host API's single-record calls)
 __global__ __launch_bounds__(64) void canon_global_one_kernel(ck::CanonArgs a, uint32_t* scratch)
 {
-    __shared__ uint32_t blk_count, lut[256];
+    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW];
     ck::fast_lut_init(lut, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
     if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
     const bool all_records = (mode & 3) == 3;                           // the streaming kernel stood this batch out
-    __shared__ uint32_t lut[256], seg_count;
+    __shared__ uint32_t lut[ck::FAST_LUT_DW], seg_count;
     ck::fast_lut_init(lut, threadIdx.x, 256);
     ck::RescueState<HASH, AUX> st;
     if (HASH) st.hc = ck::fast_hash_const();
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE
     constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && StreamC::RPW == 1 && StreamC::GROUP == 16;
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<16>() : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
-    uint32_t* blk_count = lut + 256;
+    uint32_t* blk_count = lut + ck::FAST_LUT_DW;
     uint32_t* gh = lds + StreamC::LDS_DW;
     ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
     if (GH) ck::group_hash_init(gh + 2 * 16 * ck::GH_STRIDE_DW, threadIdx.x);
@@ -400,21 +400,28 @@ __global__ __launch_bounds__(256) void uniq_insert_kernel(const uint64_t* __rest
         if (!uniq_fold(t, mask, hash[i], index ? index[i] : base + i)) atomicAdd(status, 1u);
 }
 
+// keep (nullable): keep[i] = 1 iff record base + i is the first with its hash -- the reference's "emit or table row"
+// decision (src/uniq.rs:47-62) for a shard whose record i has global index base + i
 __global__ __launch_bounds__(256) void uniq_lookup_kernel(const uint64_t* __restrict__ hash, uint64_t n, const UniqSlot* __restrict__ t, uint64_t mask,
-                                                          uint64_t* first_seen)
+                                                          uint64_t* first_seen, uint8_t* keep, uint64_t base)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t h = hash[i];
-        if (h == UNIQ_EMPTY) { first_seen[i] = t[mask + 1].val; continue; }
-        uint64_t s = uniq_slot(h, mask), probes = 0, r = UNIQ_EMPTY;
-        for (;;) {
-            const UniqSlot cur = uniq_peek(t + s);
-            if (cur.key == h) { r = cur.val; break; }
-            if (cur.key == UNIQ_EMPTY || ++probes > mask) break;
-            s = (s + 1) & mask;
+        uint64_t r = UNIQ_EMPTY;
+        if (h == UNIQ_EMPTY) {
+            r = t[mask + 1].val;
+        } else {
+            uint64_t s = uniq_slot(h, mask), probes = 0;
+            for (;;) {
+                const UniqSlot cur = uniq_peek(t + s);
+                if (cur.key == h) { r = cur.val; break; }
+                if (cur.key == UNIQ_EMPTY || ++probes > mask) break;
+                s = (s + 1) & mask;
+            }
         }
         first_seen[i] = r;
+        if (keep) keep[i] = r == base + i;
     }
 }
 
@@ -466,8 +473,8 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #define CK_TIER_B2 3324
 #endif
 constexpr int N_TIERS = 5;
-constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, 40444 };     // + 260 dwords of counter and decode table per workgroup
-constexpr uint32_t TIER_EXTRA_DW = 4 + 256;
+constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40444u : 32252u };     // + 260 dwords of counter and decode table per workgroup
+constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW;
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
 constexpr int N_CU = 256;
 
@@ -1115,7 +1122,7 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
                        c->d_table, c->uniq_mask, c->d_counters + 4);
     uint64_t* d_fs = (uint64_t*)c->d_off;          // staging reuse: offsets buffer holds >= n + 1 u64
     hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const uint64_t*)c->d_hash, n, (const UniqSlot*)c->d_table,
-                       c->uniq_mask, d_fs);
+                       c->uniq_mask, d_fs, (uint8_t*)nullptr, (uint64_t)0);
     CK_HIP(c, hipGetLastError());
     CK_HIP(c, hipMemcpyAsync(first_seen, d_fs, n * 8, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
@@ -1157,8 +1164,25 @@ int circkit_uniq_lookup_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
     if (!c->d_table) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen);
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen,
+                       (uint8_t*)nullptr, (uint64_t)0);
     CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+// One shard, one call: table reset, insert, lookup and the keep flags -- the whole first-seen resolution of a batch whose
+// record i has global index base_index + i (what `circkit uniq` decides per record on one GPU).  Only enqueues work.
+int circkit_uniq_resolve_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t n, uint64_t base_index, uint64_t* d_first_seen, uint8_t* d_keep)
+{
+    if (!c || (n && (!d_hash || !d_first_seen))) return CIRCKIT_ERR_INVALID_ARG;
+    int rc = circkit_uniq_reset(c, n);
+    if (rc || n == 0) return rc;
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, (const uint64_t*)nullptr, n, base_index,
+                       c->d_table, c->uniq_mask, c->d_counters + 4);
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen,
+                       d_keep, base_index);
+    CK_HIP(c, hipGetLastError());
+    c->uniq_count = n;
     return CIRCKIT_OK;
 }
 

@@ -12,12 +12,6 @@
 
 namespace ck {
 
-#ifndef CK_EMU
-#define CK_CONST __device__ __constant__
-#else
-#define CK_CONST static const
-#endif
-
 CK_CONST uint8_t XXH3_SECRET[192] = {
     0xb8, 0xfe, 0x6c, 0x39, 0x23, 0xa4, 0x4b, 0xbe, 0x7c, 0x01, 0x81, 0x2c, 0xf7, 0x21, 0xad, 0x1c,
     0xde, 0xd4, 0x6d, 0xe9, 0x83, 0x90, 0x97, 0xdb, 0x72, 0x40, 0xa4, 0xa4, 0xb7, 0xb3, 0x67, 0x1f,
@@ -54,14 +48,7 @@ CK_DEV uint64_t xswap64(uint64_t x)
     x = ((x & 0x0000FFFF0000FFFFull) << 16) | ((x >> 16) & 0x0000FFFF0000FFFFull);
     return (x << 32) | (x >> 32);
 }
-CK_DEV uint64_t xmulhi(uint64_t a, uint64_t b)
-{
-#ifndef CK_EMU
-    return __umul64hi(a, b);
-#else
-    return (uint64_t)(((__uint128_t)a * b) >> 64);
-#endif
-}
+CK_DEV uint64_t xmulhi(uint64_t a, uint64_t b) { return mulhi64(a, b); }
 CK_DEV uint64_t xfold(uint64_t a, uint64_t b) { return (a * b) ^ xmulhi(a, b); }
 CK_DEV uint64_t xaval3(uint64_t h) { h ^= h >> 37; h *= XPMX1; return h ^ (h >> 32); }
 CK_DEV uint64_t xaval64(uint64_t h)

@@ -58,6 +58,14 @@ class DeviceTable:
         self.ctx.uniq_lookup_device(hashes, hashes.numel(), out)
         return out
 
+    def resolve(self, hashes, base_index):
+        """reset + insert + lookup + keep flags of one shard in one library call."""
+        self._bind()
+        fs = torch.empty_like(hashes)
+        keep = torch.empty(hashes.numel(), dtype=torch.bool, device=hashes.device)
+        self.ctx.uniq_resolve_device(hashes, hashes.numel(), base_index, fs, keep)
+        return fs, keep
+
     def check(self):
         """Waits for the queued table work; raises if the table overflowed."""
         self.ctx.uniq_status()
@@ -76,6 +84,8 @@ def first_seen(table, hashes, base_index=0, group=None, exchange="partition", fo
     n = hashes.numel()
     initialised = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if initialised else 1
+    if world == 1 and not (force_exchange and initialised) and hasattr(table, "resolve"):
+        return table.resolve(hashes, base_index)
     idx = torch.arange(base_index, base_index + n, dtype=torch.int64, device=hashes.device)
     if world == 1 and not (force_exchange and initialised):
         table.reset(n)

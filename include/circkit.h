@@ -143,7 +143,12 @@ int circkit_uniq_insert_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_
  * partition, circkit_amd/uniq.py) are a subset of every other rank's shard, not a contiguous range */
 int circkit_uniq_insert_pairs_device(circkit_ctx* ctx, const uint64_t* d_hash, const uint64_t* d_index, uint64_t n);
 int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen);
-/* reset / insert / lookup only enqueue work.  circkit_uniq_status waits for it and fails with CIRCKIT_ERR_OOM when
+/* One shard in one call: reset (sized for n keys), insert with indices base_index .. base_index + n - 1, lookup, and
+ * d_keep[i] (nullable, uint8) = 1 iff d_first_seen[i] == base_index + i -- the reference's per-record decision "emit,
+ * or write a table row" (src/uniq.rs:47-62). */
+int circkit_uniq_resolve_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t base_index,
+                                uint64_t* d_first_seen, uint8_t* d_keep);
+/* reset / insert / lookup / resolve only enqueue work.  circkit_uniq_status waits for it and fails with CIRCKIT_ERR_OOM when
  * keys found no slot (more distinct keys than circkit_uniq_reset was told to expect); *n_overflowed (nullable) = how many. */
 int circkit_uniq_status(circkit_ctx* ctx, uint32_t* n_overflowed);
 

@@ -1,8 +1,8 @@
 // CPU fiber emulator for the wave-level kernels (TEST INFRASTRUCTURE ONLY, never linked into the product).
-// Compiles circkit_amd/csrc/canon_core.h with CK_EMU: each wavefront is 64 ucontext fibers scheduled
+// Compiles circkit_amd/csrc/canon_*.h against tests/emu/wave_prims_emu.h: each wavefront is 64 ucontext fibers scheduled
 // round-robin; every collective primitive is a rendezvous of all 64 fibers (a lane that skips a
 // collective deadlocks the wave, which is reported -- the same discipline the GPU build relies on).
-#define CK_EMU 1
+#define CK_WAVE_PRIMS_OVERRIDE "../../tests/emu/wave_prims_emu.h"      // (relative to circkit_amd/csrc/wave_prims.h)
 #include <ucontext.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -191,7 +191,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16 + ck::gh_lds_dw<16>()), list_f((size_t)G * cap), list_a((size_t)G * cap);
     for (uint32_t tid = 0; tid < 4; ++tid) ck::group_hash_init(lds.data() + sv->lds_dw + 2 * 16 * ck::GH_STRIDE_DW, tid);
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
-    uint32_t status = 0, lut[256];
+    uint32_t status = 0, lut[ck::FAST_LUT_DW];
     ck::fast_lut_init(lut, 0, 1);
     Launch L;
     L.a = ck::CanonArgs{};

@@ -11,7 +11,8 @@ _CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "circkit_amd", "cs
 
 
 def build():
-    srcs = [os.path.join(_HERE, "emu.cpp")] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+    srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "wave_prims_emu.h")] + \
+        [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", _SO,
                                os.path.join(_HERE, "emu.cpp")])
