@@ -225,9 +225,78 @@ struct Input {
     FILE* f = nullptr;
     bool piped = false, zstd_child = false;
     pid_t zpid = -1;
+    pid_t filter = -1, feeder = -1;    // stdin behind a decompressor: the filter process and (unseekable stdin) the one that feeds it
     const uint8_t* map = nullptr;      // regular uncompressed file: mapped, parsed in place (no read copy)
     size_t map_len = 0;
+    uint8_t prefix[8];                 // uncompressed stdin: the bytes the sniffer consumed, handed out first
+    size_t prefix_len = 0, prefix_pos = 0;
 };
+// fread() that hands out the sniffed prefix first
+size_t in_read(Input& in, uint8_t* dst, size_t n)
+{
+    size_t done = 0;
+    while (in.prefix_pos < in.prefix_len && done < n) dst[done++] = in.prefix[in.prefix_pos++];
+    if (done < n) done += fread(dst + done, 1, n - done, in.f);
+    return done;
+}
+void close_input(Input& in)
+{
+    if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
+    else if (in.zstd_child) { fclose(in.f); if (!reap_zstd(in.zpid)) die("zstd decompression of the input failed"); }
+    else if (in.filter > 0) {
+        fclose(in.f);
+        const bool ok = reap_zstd(in.filter);          // (waitpid + exit status 0)
+        if (in.feeder > 0) (void)reap_zstd(in.feeder);
+        if (!ok) die("the input decompressor failed (is it installed?)");
+    } else if (in.f != stdin) fclose(in.f);
+}
+// child process running `sh -c cmd` with stdin = in_fd; returns the read end of its stdout
+int spawn_filter(const char* cmd, int in_fd, pid_t* child)
+{
+    int pp[2];
+    if (pipe(pp) != 0) return -1;
+    fflush(stdout); fflush(stderr);
+    const pid_t pid = fork();
+    if (pid < 0) { close(pp[0]); close(pp[1]); return -1; }
+    if (pid == 0) {
+        dup2(in_fd, 0); dup2(pp[1], 1);
+        close(pp[0]); close(pp[1]); if (in_fd != 0) close(in_fd);
+        execl("/bin/sh", "sh", "-c", cmd, (char*)nullptr);
+        _exit(127);
+    }
+    *child = pid;
+    close(pp[1]);
+    return pp[0];
+}
+// child process that replays `head` and then forwards the rest of fd 0; returns the read end
+int spawn_feeder(const uint8_t* head, size_t n, pid_t* child)
+{
+    int pp[2];
+    if (pipe(pp) != 0) return -1;
+    fflush(stdout); fflush(stderr);
+    const pid_t pid = fork();
+    if (pid < 0) { close(pp[0]); close(pp[1]); return -1; }
+    if (pid == 0) {
+        close(pp[0]);
+        static uint8_t buf[1 << 20];
+        size_t have = n;
+        memcpy(buf, head, n);
+        for (;;) {
+            for (size_t off = 0; off < have;) {
+                const ssize_t w = write(pp[1], buf + off, have - off);
+                if (w < 0) { if (errno == EINTR) continue; _exit(1); }
+                off += (size_t)w;
+            }
+            ssize_t r;
+            while ((r = read(0, buf, sizeof buf)) < 0 && errno == EINTR) {}
+            if (r <= 0) _exit(r < 0);
+            have = (size_t)r;
+        }
+    }
+    *child = pid;
+    close(pp[1]);
+    return pp[0];
+}
 
 const char* sniff(const uint8_t* m, size_t n)
 {
@@ -243,7 +312,34 @@ Input open_input(const Options& o)
     Input in;
     if (!o.has_input) {
         if (isatty(0)) die("No stdin detected. Did you mean to include a file argument?");     // src/utils.rs:18-20
+        // niffler::send::get_reader wraps stdin as well (src/utils.rs:21-24): `circkit canonicalize < in.fasta.gz` works
+        // there.  Sniff the first bytes straight from the descriptor (nothing is buffered in `stdin` yet).
+        uint8_t magic[6];
+        size_t got = 0;
+        while (got < sizeof magic) {
+            const ssize_t r = read(0, magic + got, sizeof magic - got);
+            if (r < 0 && errno == EINTR) continue;
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        const char* tool = sniff(magic, got);
         in.f = stdin;
+        if (!tool) { memcpy(in.prefix, magic, got); in.prefix_len = got; return in; }
+        int src = 0;                                 // a redirected file: rewind; a pipe: a feeder child replays the sniffed bytes
+        if (lseek(0, 0, SEEK_SET) != 0) {
+            src = spawn_feeder(magic, got, &in.feeder);
+            if (src < 0) die("could not start the stdin feeder");
+        }
+        int pfd = -1;
+        if (!strcmp(tool, "zstd")) {
+            pfd = spawn_zstd(src == 0 ? dup(0) : src, false, 0, &in.zpid);
+            if (pfd >= 0) { in.f = fdopen(pfd, "rb"); in.zstd_child = true; return in; }
+            if (src != 0) die("zstd decompression of stdin is not available");
+        }
+        pfd = spawn_filter((std::string(tool) + " -dc").c_str(), src, &in.filter);
+        if (pfd < 0) die(std::string("could not run ") + tool + " to decompress the input");
+        if (src != 0) close(src);
+        in.f = fdopen(pfd, "rb");
         return in;
     }
     FILE* f = fopen(o.input.c_str(), "rb");
@@ -407,7 +503,7 @@ int run_host_edit(const Options& opt, Input& in, Output& out)
     if (!text) {
         uint8_t buf[1 << 16];
         size_t got;
-        while ((got = fread(buf, 1, sizeof buf, in.f)) > 0) owned.insert(owned.end(), buf, buf + got);
+        while ((got = in_read(in, buf, sizeof buf)) > 0) owned.insert(owned.end(), buf, buf + got);
         text = owned.data();
         len = owned.size();
     }
@@ -456,9 +552,7 @@ int run_host_edit(const Options& opt, Input& in, Output& out)
         }
     }
     close_output(out);
-    if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
-    else if (in.zstd_child) { fclose(in.f); if (!reap_zstd(in.zpid)) die("zstd decompression of the input failed"); }
-    else if (in.f != stdin) fclose(in.f);
+    close_input(in);
     return 0;
 }
 
@@ -539,7 +633,7 @@ int main(int argc, char** argv)
                 size_t cut = 0;
                 for (;;) {
                     while (!eof && have < s.own.size()) {
-                        const size_t got = fread(s.own.data() + have, 1, s.own.size() - have, in.f);
+                        const size_t got = in_read(in, s.own.data() + have, s.own.size() - have);
                         if (got == 0) { if (ferror(in.f)) die("failed to read the input"); eof = true; }
                         have += got;
                     }
@@ -669,9 +763,7 @@ int main(int argc, char** argv)
                 n_parsers, g_gpu.s(), g_write.s());
     close_output(out);
     if (table) fclose(table);
-    if (in.piped) { if (pclose(in.f) != 0) die("the input decompressor failed (is it installed?)"); }
-    else if (in.zstd_child) { fclose(in.f); if (!reap_zstd(in.zpid)) die("zstd decompression of the input failed"); }
-    else if (in.f != stdin) fclose(in.f);
+    close_input(in);
     for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }   // pinned memory goes before the ctx
     circkit_ctx_destroy(ctx);
     return 0;

@@ -72,3 +72,11 @@ def test_product_does_not_reference_the_oracle():
         for f in files:
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 assert "oracle" not in open(os.path.join(dirpath, f), errors="ignore").read().lower(), f
+
+
+def test_integration_md_binds_every_declared_symbol():
+    """INTEGRATION.md section 2 is the reference-side binding: it must declare exactly the header's symbols."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("## 2. Declarations"):text.index("## 3. Drop-in")]
+    bound = sorted(set(re.findall(r"pub fn (circkit_[a-z0-9_]+)\s*\(", block)))
+    assert bound == header_symbols()

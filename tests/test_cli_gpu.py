@@ -100,6 +100,20 @@ def test_compressed_input(command, ext, tool, tmp_path):
     assert id_seq_map(out.read_bytes()) == id_seq_map(open(fixture("compressed_input", "out.fasta"), "rb").read())
 
 
+@pytest.mark.parametrize("ext,tool", [("gz", "gzip"), ("bz2", "bzip2"), ("xz", "xz"), ("zst", "zstd")])
+def test_compressed_stdin(ext, tool, tmp_path):
+    """src/utils.rs:21-24: stdin goes through niffler too -- `circkit canonicalize < in.fasta.gz` and a pipe."""
+    if tool != "zstd" and not shutil.which(tool):
+        pytest.skip("%s is not installed on this box" % tool)
+    want = id_seq_map(open(fixture("compressed_input", "out.fasta"), "rb").read())
+    src = fixture("compressed_input", "in.fasta." + ext)
+    with open(src, "rb") as f:
+        r = subprocess.run([BIN, "canonicalize"], stdin=f, capture_output=True, timeout=120)
+    assert r.returncode == 0 and id_seq_map(r.stdout) == want, r.stderr
+    r = run("canonicalize", stdin=open(src, "rb").read())
+    assert r.returncode == 0 and id_seq_map(r.stdout) == want, r.stderr
+
+
 def test_uniq_table_and_raw_output(tmp_path):
     """src/uniq.rs:50-70: without --canonicalize the kept record prints its RAW bytes; duplicates become table rows."""
     from oracle import oracle as O

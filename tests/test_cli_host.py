@@ -131,3 +131,38 @@ def test_zstd_streams_without_the_zstd_binary(tmp_path):
     (tmp_path / "cut.fasta.zst").write_bytes(raw[:len(raw) // 2])
     r = run("cat", str(tmp_path / "cut.fasta.zst"))
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("ext", ["gz", "bz2", "xz", "zst"])
+def test_compressed_stdin_is_sniffed(ext, tmp_path):
+    """src/utils.rs:21-24: niffler wraps stdin too, so `circkit cat < in.fasta.gz` and `... | circkit cat` both
+    decode.  Redirected file (seekable: rewound) and pipe (a feeder child replays the sniffed bytes); a 3 MB stream as
+    well, and short plain inputs whose first bytes the sniffer consumed."""
+    import gzip, bz2, lzma
+    import numpy as np
+    src = os.path.join(GOLDEN, "compressed_input", "in.fasta." + ext)
+    plain = open(os.path.join(GOLDEN, "compressed_input", "in.fasta"), "rb").read()
+    want = O.cli_cat(plain)
+    with open(src, "rb") as f:                                   # redirected file
+        r = subprocess.run([BIN, "cat"], stdin=f, capture_output=True, timeout=60)
+    assert (r.returncode, r.stdout) == (0, want), r.stderr
+    r = run("cat", stdin=open(src, "rb").read())                 # pipe
+    assert (r.returncode, r.stdout) == (0, want), r.stderr
+    rng = np.random.default_rng(5)
+    big = b"".join(b">r%d\n" % i + bytes(rng.choice(list(b"ACGT"), size=5000).astype(np.uint8)) + b"\n" for i in range(600))
+    if ext == "zst":
+        import pyarrow as pa
+        sink = pa.BufferOutputStream()
+        with pa.CompressedOutputStream(sink, "zstd") as z:
+            z.write(big)
+        packed = sink.getvalue().to_pybytes()
+    else:
+        packed = {"gz": gzip.compress, "bz2": bz2.compress, "xz": lzma.compress}[ext](big)
+    r = run("cat", stdin=packed)
+    assert (r.returncode, r.stdout) == (0, O.cli_cat(big)), r.stderr[:300]
+
+
+def test_plain_stdin_keeps_the_sniffed_bytes():
+    for data in (b">a\nA\n", b">ab\nACGT\n>c\nTT", b">x\n"):
+        r = run("cat", stdin=data)
+        assert (r.returncode, r.stdout) == (0, O.cli_cat(data)), (data, r.stderr)
