@@ -210,8 +210,7 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
     // first is consumed: a long record is otherwise one exposed HBM round trip per row (measured: tier B of
     // BASELINE config 4 spent 61 % of its wave cycles in s_waitcnt with the VALU 20 % busy).
     constexpr int U = CK_BUILD_ROWS;
-    for (uint32_t base = 0; base < nwv; base += 64 * U) {          // wave-uniform trip count (the early exit below is a collective)
-        const uint32_t w0 = base + lane;
+    for (uint32_t w0 = lane; w0 < nwv; w0 += 64 * U) {
         u32x4 vf[U], vc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -244,8 +243,6 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
                 }
             }
         }
-        // a byte outside the alphabet: no point in packing the rest (with 1 % N the first rows of a long record show it)
-        if (ballot(bad != 0) != 0) break;
     }
     const bool ok = ballot(bad != 0) == 0;
     wave_sync();
@@ -331,22 +328,22 @@ CK_DEV uint32_t next_cand(const uint32_t* bm, uint32_t x, uint32_t n)
 }
 
 // ------------------------------------------------------------------------------------------------
-// smallest index of the lexicographically minimal rotation + the rotation period
+// dense scan of one strand and the unique-minimum shortcut; `word_at(p)` = the S symbols at cyclic position p < 2n
 // ------------------------------------------------------------------------------------------------
-template <int BITS, bool RCV>
-CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
+struct ScanMin { uint32_t M; uint64_t hm; uint32_t bestw, ties; };     // wave minimum key, lanes holding it; per lane: its word, ties
+// per-lane minimum key, which word owns it, and how many of the lane's words tie.  Every word is fetched once: the
+// word behind it is the next lane's (DPP), lane 63's the first word of the next row.
+template <int BITS, class WordAt>
+CK_DEV ScanMin dense_scan(WordAt word_at, uint32_t n)
 {
     constexpr uint32_t S = 32 / BITS;
     const uint32_t lane = lane_id();
     const uint32_t nwv = (n + S - 1) / S;
-
-    // dense scan: per-lane minimum key, which word owns it, and how many of the lane's words tie.  Every word is
-    // fetched once: the word behind it is the next lane's (DPP), lane 63's the first word of the next row.
     uint32_t best = ~0u, bestw = 0, ties = 0;
-    uint32_t cur = lane < nwv + 1 ? view_word<BITS, RCV>(E, lane * S, n) : 0u;
+    uint32_t cur = lane < nwv + 1 ? word_at(lane * S) : 0u;
     for (uint32_t w0 = 0; w0 < nwv; w0 += 64) {
         const uint32_t w = w0 + lane;
-        const uint32_t ahead = w + 64 < nwv + 1 ? view_word<BITS, RCV>(E, (w + 64) * S, n) : 0u;     // this lane's word of the next row
+        const uint32_t ahead = w + 64 < nwv + 1 ? word_at((w + 64) * S) : 0u;                     // this lane's word of the next row
         const uint32_t first_of_next_row = readlane(ahead, 0), neighbour = wave_shl1(cur);      // (collectives: every lane, unconditionally)
         const uint32_t nxt = lane == 63 ? first_of_next_row : neighbour;
         if (w < nwv) {
@@ -356,27 +353,51 @@ CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
         }
         cur = ahead;
     }
-    const uint32_t M = wave_min_u32(best);
-    const uint64_t hm = ballot(ties != 0 && best == M);
+    ScanMin r;
+    r.M = wave_min_u32(best);
+    r.hm = ballot(ties != 0 && best == r.M);
+    r.bestw = bestw; r.ties = ties;
+    return r;
+}
+// at most two words hold M (the second is normally the duplicate of word 0's positions that sits behind the record
+// end in the last word) and exactly one valid position owns it: that position
+template <int BITS, class WordAt>
+CK_DEV bool locate_unique(WordAt word_at, uint32_t n, const ScanMin& sm, uint32_t& pos)
+{
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t lane = lane_id();
+    if (popc64(sm.hm) > 2) return false;
+    uint32_t cnt = 0;
+    uint64_t mm = sm.hm;
+    while (mm) {
+        const uint32_t l = (uint32_t)ffs64(mm);
+        mm &= mm - 1;
+        const uint32_t tl = readlane(sm.ties, l), wl = readlane(sm.bestw, l);
+        if (tl != 1) return false;
+        const uint32_t b = lane % S;
+        const uint32_t k = word_at(wl * S + b);
+        const uint64_t pm = ballot(lane < S && k == sm.M && wl * S + b < n);
+        cnt += (uint32_t)popc64(pm);
+        if (pm) pos = wl * S + (uint32_t)ffs64(pm);
+    }
+    return cnt == 1;
+}
 
-    // fast path: at most two words hold M (the second is normally the duplicate of word 0's positions
-    // that sits behind the record end in the last word) and exactly one valid position owns it.
-    if (popc64(hm) <= 2) {
-        uint32_t cnt = 0, pos = 0;
-        bool multi = false;
-        uint64_t mm = hm;
-        while (mm) {
-            const uint32_t l = (uint32_t)ffs64(mm);
-            mm &= mm - 1;
-            const uint32_t tl = readlane(ties, l), wl = readlane(bestw, l);
-            if (tl != 1) { multi = true; break; }
-            const uint32_t b = lane % S;
-            const uint32_t k = view_word<BITS, RCV>(E, wl * S + b, n);
-            const uint64_t pm = ballot(lane < S && k == M && wl * S + b < n);
-            cnt += (uint32_t)popc64(pm);
-            if (pm) pos = wl * S + (uint32_t)ffs64(pm);
-        }
-        if (!multi && cnt == 1) return RotResult{ pos, n };
+// ------------------------------------------------------------------------------------------------
+// smallest index of the lexicographically minimal rotation + the rotation period
+// ------------------------------------------------------------------------------------------------
+template <int BITS, bool RCV>
+CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
+{
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t lane = lane_id();
+    const uint32_t nwv = (n + S - 1) / S;
+    const auto word_at = [&](uint32_t p) { return view_word<BITS, RCV>(E, p, n); };
+    const ScanMin sm = dense_scan<BITS>(word_at, n);
+    const uint32_t M = sm.M;
+    {
+        uint32_t pos = 0;
+        if (locate_unique<BITS>(word_at, n, sm, pos)) return RotResult{ pos, n };
     }
 
     // general path.  1: candidate bitmask = positions whose key equals M
@@ -521,12 +542,144 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// 2-bit mode for records with a FEW N ("2N"): the reference sorts N like any other byte (between G and T,
+// lib/src/canonicalize.rs:50-53), but one N in 20 kb should not push the record into the 4-bit mode at 2-3x the cost.
+// N is packed as G and remembered in a second strand of masks (0b11 at every N).  Every key that holds an N is then
+// SMALLER than or equal to its true value (G < N), and every other key is exact, so:
+//   * if the smaller of the two strands' minimal keys is owned by exactly one position whose 16-symbol window is
+//     N-free, that position is the true minimal rotation of the true winning strand (any window with an N has a true
+//     key above its packed key >= that minimum; the other strand's true minimum is above its packed minimum);
+//   * anything else -- equal minimal keys, a tie, an N inside the winning window -- is left to the 4-bit mode.
+// The reverse-strand view complements G to C where the forward strand held an N; the mask strand, read through the
+// same window and bit-reversed, turns that C back into G.  Output bytes are patched from 'G' to 'N' by a second table.
+// ------------------------------------------------------------------------------------------------
+// 16 ASCII bytes -> 16 two-bit codes with N -> G, the N mask (0b11 per N), miss != 0 iff a byte is outside ACGTN
+CK_DEV uint32_t fast_pack_n(u32x4 v, uint32_t& nmask, uint32_t& miss)
+{
+    const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+    uint32_t u[4], m[4];
+    miss = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sel = (d[k] >> 1) & HASH_MASK;                       // A0 C1 T2 G3 ... N7
+        miss = sad_u8(perm(0x4E000000u, CHK2_LO, sel), d[k], miss);
+        u[k] = udot4(perm(0x02000000u, 0x02030100u, sel), 0x01041040u, 0u);
+        m[k] = udot4((sel >> 2) & 0x01010101u, 0x030C30C0u, 0u);            // selector bit 2: N (everything else up there is refused)
+    }
+    nmask = (((m[0] << 8 | m[1]) << 8 | m[2]) << 8) | m[3];
+    return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
+}
+// 256-entry LDS table: mask byte (4 symbols, 0b11 per N) -> the XOR that turns a decoded 'G' into 'N' in those bytes
+CK_DEV void fast_lutn_init(uint32_t* lutn, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t x = tid; x < 256; x += nthreads) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o |= (((x >> (6 - 2 * k)) & 1u) * 0x09u) << (8 * k);     // 'G' ^ 'N' = 0x09
+        lutn[x] = o;
+    }
+}
+// forward words + mask words (+ the periodic extension of both); returns false when a byte is outside ACGTN
+CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Nm)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
+    uint32_t bad = 0;
+    constexpr int U = CK_BUILD_ROWS;
+    for (uint32_t w0 = lane; w0 < nwv; w0 += 64 * U) {
+        u32x4 vf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w = w0 + 64 * u;
+            if (w < nwv) vf[u] = load16(src + (w >= nwf ? n - 16 : w * 16));        // the tail word reads the record's last 16 bytes
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w = w0 + 64 * u;
+            if (w < nwv) {
+                const uint32_t sh = w >= nwf ? (16 - r) * 2 : 0u;
+                uint32_t nm, miss;
+                Ef[w] = fast_pack_n(vf[u], nm, miss) << sh;
+                Nm[w] = nm << sh;
+                bad |= miss;
+            }
+        }
+    }
+    const bool ok = ballot(bad != 0) == 0;
+    wave_sync();
+    if (lane < 3) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t* E = s ? Nm : Ef;
+            if (lane == 0) {
+                if (r) E[nwf] = E[nwf] | (E[0] >> (r * 2));
+            } else {
+                const uint32_t e = lane - 1;
+                E[nwv + e] = r ? funnel(E[e], E[e + 1], (16 - r) * 2) : E[e];
+            }
+        }
+    }
+    wave_sync();
+    return ok;
+}
+CK_DEV uint32_t need_dw_2n(uint32_t n) { return 2 * ((n + 15) / 16 + 2) + 1; }
+
+// 0: done; 1: leave it to the 4-bit mode (a byte outside ACGTN, or one of the cases listed above)
+CK_DEV int canon_record_mode2n(const CanonArgs& a, uint64_t rec, const uint8_t* src, uint64_t off, uint32_t n, uint32_t* lds,
+                               const uint32_t* lut, const uint32_t* lutn)
+{
+    const uint32_t nwv = (n + 15) / 16;
+    uint32_t* Ef = lds;
+    uint32_t* Nm = lds + (nwv + 2);
+    if (!build_packed2n(src, n, Ef, Nm)) return 1;
+    const auto mirror = [&](uint32_t p) {                   // start of the forward window behind reverse-strand position p
+        p = p >= n ? p - n : p;
+        const int32_t s0 = (int32_t)n - 16 - (int32_t)p;
+        return (uint32_t)(s0 + ((s0 >> 31) & (int32_t)n));
+    };
+    const auto fwd_at = [&](uint32_t p) { return sym_word<2>(Ef, p, n); };
+    const auto rc_at = [&](uint32_t p) { const uint32_t s = mirror(p); return rc_word<2>(sym_word<2>(Ef, s, n)) ^ bitrev(sym_word<2>(Nm, s, n)); };
+    const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
+    const ScanMin sf = dense_scan<2>(fwd_at, n);
+    ScanMin sc = sf;
+    if (!fwd_only) {
+        sc = dense_scan<2>(rc_at, n);
+        if (sf.M == sc.M) return 1;
+    }
+    const bool fwd = fwd_only || sf.M < sc.M;
+    uint32_t pos = 0, fpos = 0;
+    const bool uq = fwd ? locate_unique<2>(fwd_at, n, sf, pos) : locate_unique<2>(rc_at, n, sc, pos);
+    if (!uq) return 1;
+    if (sym_word<2>(Nm, fwd ? pos : mirror(pos), n) != 0) return 1;            // an N inside the winning window
+    if (!fwd && a.out_index) {                                                  // the reference-visible index counts from the forward minimum
+        if (!locate_unique<2>(fwd_at, n, sf, fpos) || sym_word<2>(Nm, fpos, n) != 0) return 1;
+    }
+    if (a.out_bytes) {
+        uint8_t* out = a.out_bytes + off;
+        for (uint32_t w = lane_id(); w < nwv; w += 64) {
+            const uint32_t p = pos + w * 16;
+            const uint32_t v = fwd ? fwd_at(p) : rc_at(p);
+            const uint32_t m = fwd ? sym_word<2>(Nm, p, n) : bitrev(sym_word<2>(Nm, mirror(p), n));
+            u32x4 o = fast_decode(lut, v);
+            o.x ^= lutn[m >> 24]; o.y ^= lutn[(m >> 16) & 0xFF]; o.z ^= lutn[(m >> 8) & 0xFF]; o.w ^= lutn[m & 0xFF];
+            const uint32_t left = n - w * 16;
+            store_bytes(out + w * 16, o, left < 16 ? left : 16);
+        }
+    }
+    if (lane_id() == 0) {
+        if (a.out_index) a.out_index[rec] = fwd ? pos : (pos + fpos) % n;        // unique minimum: period n
+        if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+    }
+    return 0;
+}
+
 // List entries: bits 0..30 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
 // that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte).
 constexpr uint32_t ENTRY_NOT_ACGT = 0x80000000u, ENTRY_REC = 0x7FFFFFFFu;
 
 // Processes one record; returns false if it does not fit this tier's LDS slice (not_acgt then says what was learnt).
-CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, bool& not_acgt)
+CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, bool& not_acgt)
 {
     const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
     if (len >> 31) return false;                 // 32-bit cyclic positions (p < 2n): a record of 2 Gi symbols or more fits nowhere
@@ -542,8 +695,24 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
     if (n >= 48) {
         if (!not_acgt) {
             if (need_dw<2>(n) > a.slice_dw) return false;
-            if (canon_record_mode<2>(a, rec, src, off, n, lds, lut)) return true;
-            not_acgt = true;
+            // a look at the first KiB before the strand is built: with N sprinkled in at 1 %, that is where a long
+            // record shows it (its bytes are in the cache for the builder afterwards)
+            uint32_t miss = 0;
+            if (16 * lane_id() + 16 <= n) (void)fast_pack(load16(src + 16 * lane_id()), miss);
+            not_acgt = ballot(miss != 0) != 0;
+            if (!not_acgt) {
+                if (canon_record_mode<2>(a, rec, src, off, n, lds, lut)) return true;
+                not_acgt = true;
+            }
+        }
+        // a few N: 2-bit words + a mask strand (0 = done; else the 4-bit mode decides, here or in a bigger tier)
+#ifdef CK_NO_2N
+        if (false) {
+#else
+        if (lutn && need_dw_2n(n) <= a.slice_dw) {
+#endif
+            if (canon_record_mode2n(a, rec, src, off, n, lds, lut, lutn) == 0) return true;
+            wave_sync();            // every lane has read the strands before the next mode overwrites them
         }
         if (need_dw<4>(n) > a.slice_dw) return false;
         if (canon_record_mode<4>(a, rec, src, off, n, lds, lut)) return true;
@@ -565,12 +734,12 @@ CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block
 // loop of one wave (wave `wib` of `wpb` in workgroup `block` of `nblocks`) over its share of the work.
 // (Loading the next record's list entry and offsets one record ahead was tried and measured: no gain.)
 CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, uint32_t* blk_count, uint32_t block,
-                            uint32_t nblocks, uint32_t wib, uint32_t wpb)
+                            uint32_t nblocks, uint32_t wib, uint32_t wpb, const uint32_t* lutn = nullptr)
 {
     if (!a.list) {
         for (uint64_t rec = (uint64_t)block * wpb + wib; rec < a.n_records; rec += (uint64_t)nblocks * wpb) {
             bool not_acgt = false;
-            if (!canon_record(a, rec, lds, lut, not_acgt)) defer_record(a, blk_count, block, (uint32_t)rec, not_acgt);
+            if (!canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, (uint32_t)rec, not_acgt);
             wave_sync();
         }
         return;
@@ -581,7 +750,7 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
         for (uint32_t i = wib; i < count; i += wpb) {
             const uint32_t rec = seg[i] & ENTRY_REC;
             bool not_acgt = (seg[i] & ENTRY_NOT_ACGT) != 0;
-            if (!canon_record(a, rec, lds, lut, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
+            if (!canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
             wave_sync();
         }
     }

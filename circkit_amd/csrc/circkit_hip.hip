@@ -34,13 +34,18 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // One wavefront per record, WPB wavefronts per workgroup, each with its own LDS slice; the last LDS dword is the
 // workgroup's deferral counter.  Consumes the segmented list of the previous stage (or all records).
+#ifndef CK_TIER_WPE
+#define CK_TIER_WPE 7      // min waves per SIMD the LDS-tier kernels are compiled for: 72 VGPRs, no spills (measured: 1 -> 76 VGPRs / 6 waves +2.7 %, 8 -> spills +1.2 %)
+#endif
 template <int WPB>
-__global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32_t nvb, uint32_t* giants)
+__global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonArgs a, uint32_t nvb, uint32_t* giants)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + WPB * a.slice_dw;
     uint32_t* lut = blk_count + 4;                   // 2-bit decode table shared by the workgroup's waves
+    uint32_t* lutn = lut + ck::FAST_LUT_DW;          // ...and the 'G' -> 'N' patch table of the 2-bit-with-N-mask mode
     ck::fast_lut_init(lut, threadIdx.x, WPB * 64);
+    ck::fast_lutn_init(lutn, threadIdx.x, WPB * 64);
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     // `nvb` virtual workgroups (one output segment each) walked by a grid that is no bigger than what keeps the chip
     // busy: on the batches where these tiers have nothing to do (the headline) one workgroup per segment was 12-28 us of
@@ -48,7 +53,7 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32
     for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
-        ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, vb, nvb, wib, WPB);
+        ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, vb, nvb, wib, WPB, lutn);
         __syncthreads();
         if (threadIdx.x == 0 && a.defer_count) a.defer_count[vb] = *blk_count;
         if (threadIdx.x == 0 && giants && *blk_count) atomicAdd(giants, *blk_count);     // last LDS tier: tell the global-scratch kernel there is work
@@ -67,11 +72,12 @@ __global__ __launch_bounds__(WPB * 64) void canon_kernel(ck::CanonArgs a, uint32
 __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::CanonArgs a2, uint32_t* scratch, uint32_t* ticket, const uint32_t* giants)
 {
     if (*giants == 0) return;           // nothing came out of the last LDS tier (every ordinary batch): the launch costs ~3 us, not ~12
-    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], last;
+    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[256], last;
     ck::fast_lut_init(lut, threadIdx.x, 64);
+    ck::fast_lutn_init(lutn, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
-    ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1);
+    ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1, lutn);
     __syncthreads();
     if (threadIdx.x == 0) {
         a.defer_count[blockIdx.x] = blk_count;
@@ -90,17 +96,18 @@ __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::C
     if (!last) return;
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
-    ck::canon_wave_loop(a2, scratch, lut, &blk_count, 0, 1, 0, 1);           // no output list: leftovers are counted in status[0]
+    ck::canon_wave_loop(a2, scratch, lut, &blk_count, 0, 1, 0, 1, lutn);     // no output list: leftovers are counted in status[0]
 }
 
 // one record in global scratch (the host API's single-record calls)
 __global__ __launch_bounds__(64) void canon_global_one_kernel(ck::CanonArgs a, uint32_t* scratch)
 {
-    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW];
+    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[256];
     ck::fast_lut_init(lut, threadIdx.x, 64);
+    ck::fast_lutn_init(lutn, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
     __syncthreads();
-    ck::canon_wave_loop(a, scratch, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1);
+    ck::canon_wave_loop(a, scratch, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1, lutn);
 }
 
 // XXH3-64 of the listed records (the ones canon_global_kernel finished after the batch's own hash pass)
@@ -467,14 +474,14 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #define CK_TIER_A 1023
 #endif
 #ifndef CK_TIER_B1
-#define CK_TIER_B1 2300
+#define CK_TIER_B1 1900     // 2-bit records up to ~20.2 kb (one stored strand): all of BASELINE config 4 behind tier A
 #endif
 #ifndef CK_TIER_B2
 #define CK_TIER_B2 3324
 #endif
 constexpr int N_TIERS = 5;
-constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40444u : 32252u };     // + 260 dwords of counter and decode table per workgroup
-constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW;
+constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40188u : 31996u };     // + 260 dwords of counter and decode table per workgroup
+constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW + 256;        // counter, decode table, N patch table
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
 constexpr int N_CU = 256;
 

@@ -4,6 +4,7 @@
 // collective deadlocks the wave, which is reported -- the same discipline the GPU build relies on).
 #define CK_WAVE_PRIMS_OVERRIDE "../../tests/emu/wave_prims_emu.h"      // (relative to circkit_amd/csrc/wave_prims.h)
 #include <ucontext.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -57,8 +58,26 @@ void gather(uint64_t v, uint64_t out[64])
     WaveSync& w = B->ws[f >> 6];
     const uint32_t g = B->gen[f]++;
     const int s = g & 1;
+#ifdef CK_EMU_CHECK_SITES
+    // every lane must be in the SAME collective: compare the call sites (build with -O0 -DCK_EMU_CHECK_SITES)
+    static void* site[MAXW][2][64];
+    site[f >> 6][s][l] = __builtin_return_address(1);
+    if (w.cnt[s] > 0 && site[f >> 6][s][l] != site[f >> 6][s][(l + 63) & 63] && false) {}
+#endif
     w.buf[s][l] = v;
-    if (++w.cnt[s] == 64) { w.complete[s] = g; w.cnt[s] = 0; }
+    if (++w.cnt[s] == 64) {
+#ifdef CK_EMU_CHECK_SITES
+        for (int i = 1; i < 64; ++i)
+            if (site[f >> 6][s][i] != site[f >> 6][s][0]) {
+                Dl_info base;
+                dladdr((void*)&gather, &base);              // offsets into the shared object: addr2line -f -C -e libcanon_emu.so <offset>
+                fprintf(stderr, "emu: lanes 0 and %d are in different collectives: %#lx vs %#lx\n", i,
+                        (unsigned long)((char*)site[f >> 6][s][0] - (char*)base.dli_fbase), (unsigned long)((char*)site[f >> 6][s][i] - (char*)base.dli_fbase));
+                abort();
+            }
+#endif
+        w.complete[s] = g; w.cnt[s] = 0;
+    }
     while (w.complete[s] != g) yield_next("wave collective");
     for (int i = 0; i < 64; ++i) out[i] = w.buf[s][i];
 }
@@ -120,11 +139,11 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false; };
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false; };
 void wave_body(void* p)
 {
     Launch* L = (Launch*)p;
-    ck::canon_wave_loop(L->a, L->lds, L->lut, L->blk_count, L->block, L->nblocks, L->wib, 4);
+    ck::canon_wave_loop(L->a, L->lds, L->lut, L->blk_count, L->block, L->nblocks, L->wib, 4, L->lutn);
 }
 void rescue_body(void* p)
 {
@@ -193,6 +212,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[ck::FAST_LUT_DW];
     ck::fast_lut_init(lut, 0, 1);
+    uint32_t lutn[256];
+    ck::fast_lutn_init(lutn, 0, 1);
     Launch L;
     L.a = ck::CanonArgs{};
     L.a.bytes = bytes; L.a.offsets = offsets; L.a.n_records = n_records;
@@ -201,7 +222,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a.hashed = hashed.data();
     L.a.status = &status; L.a.comp_lut = comp; L.a.flags = flags;
     L.a.defer_list = list_f.data(); L.a.defer_count = cnt_f.data(); L.a.out_seg_cap = cap;
-    L.lds = lds.data(); L.lut = lut; L.nblocks = G;
+    L.lds = lds.data(); L.lut = lut; L.lutn = lutn; L.nblocks = G;
     uint32_t total_f = 0, total_a = 0;
     for (uint32_t b = 0; b < G && !all_records; ++b) {
         uint32_t blk = 0;

@@ -252,3 +252,36 @@ def test_four_bit_register_path_takes_n_and_gap_records():
             assert out[a:b].tobytes() == want[i][0], (i, len(s), s[:40])
             if want_hash:
                 assert int(h[i]) == O.xxh3_64(want[i][0])
+
+
+def test_two_bit_mode_with_n_mask_in_the_lds_tiers():
+    """Long records with a few N: 2-bit words + a mask strand (canon_record_mode2n); N packs as G, so the cases where
+    that matters must fall back to the 4-bit mode and still come out right: an N inside the minimal window, minimal
+    windows that differ only by N vs G, ties in the packed space, '-' (sorts below A), N-only stretches."""
+    rng = np.random.default_rng(1200)
+    seqs = []
+    for L in (1100, 1500, 2047, 2048, 2049, 3000, 4097, 6000):
+        for frac in (0.001, 0.01, 0.05):
+            s = bytearray(seqsets.random_mixed(1201 + L, 1, L, L)[0])
+            for p in rng.integers(0, L, size=max(1, int(L * frac))):
+                s[int(p)] = ord("N")
+            seqs.append(bytes(s))
+    body = seqsets.random_mixed(1202, 1, 2000, 2000)[0].replace(b"AAAA", b"ACAC")
+    seqs += [b"AAAAAAAANAAAAAAAAAAA" + body,                       # the N sits in what packs as the minimal window
+             b"AAAAAAAAAAAAAAAAAAAAG" + body + b"AAAAAAAAAAAAAAAAAAAAN" + body,     # ...GAAAA vs ...NAAAA: N > G decides
+             b"AAAAAAAAAAAAAAAAAAAAN" + body + b"AAAAAAAAAAAAAAAAAAAAG" + body,
+             b"N" * 1500, b"ACGTN" * 400, b"A" * 1200 + b"N", b"N" + b"T" * 1300,
+             b"-" + body, body[:1000] + b"-N" + body[1000:]]
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    for want_aux, slice_dw in ((False, 1023), (True, 1023), (False, 9980)):
+        out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=want_aux, staged=0, slice_dw=slice_dw,
+                                                                   n_waves=8, alpha=False)
+        for i, s in enumerate(seqs):
+            if strand[i] == 0xFF and want_aux:          # deferred: does not fit this slice
+                continue
+            a, b = int(offs[i]), int(offs[i + 1])
+            if want_aux or slice_dw == 9980:
+                assert out[a:b].tobytes() == want[i][0], (i, len(s), s[:30])
+            if want_aux:
+                assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, len(s))
