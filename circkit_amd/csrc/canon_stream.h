@@ -83,10 +83,13 @@ CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, u
 // loop of one wave of a workgroup; every wave of the workgroup runs the same number of iterations (barriers inside).
 // GH: XXH3 is finished per record group by one wave (canon_fast.h, group_hash_*); gh = its LDS area (gh_lds_dw<GROUP>()
 // dwords, constants initialised by group_hash_init).
-template <class C, bool HASH, bool AUX, bool GH = false>
+// ALPHA: records with a byte outside ACGT take the 4-bit register routine here (fast_canonw<4>) instead of being
+// deferred -- the build for batches whose mode carries MODE_ALPHA.
+template <class C, bool HASH, bool AUX, bool GH = false, bool ALPHA = false>
 CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint32_t* ring, uint32_t* blk_count, uint32_t block,
                                    uint32_t nblocks, uint32_t* gh = nullptr)
 {
+    static_assert(!ALPHA || !AUX, "index / strand outputs: the 4-bit records take the LDS tiers");
     static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
     static_assert(!GH || (HASH && C::RPW == 1 && C::GROUP == 16), "the group merger takes 16 records, one per wave");
     constexpr int D = C::NBUF - 1;                    // groups in flight
@@ -153,11 +156,23 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 // the byte funnel is done on the packed words: 2*a16 bits, with the next lane's word behind
                 const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;
                 uint32_t miss;
-                const uint32_t P = fast_pack(lds_load16(img + 4 * ((rel >> 4) + t)), miss);
+                const u32x4 v = lds_load16(img + 4 * ((rel >> 4) + t));
+                const uint32_t P = fast_pack(v, miss);
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
                 const uint64_t bad = ballot(miss != 0) & (~0ull >> (64 - nch));         // 3 <= nch <= 64
-                done = fast_canon<HASH, AUX>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
+                if (ALPHA && bad != 0) {
+                    // {-,A,C,G,N,T} at 4 bits per symbol: 64 bits per lane, the record's offset in its first chunk
+                    // removed by a 128-bit funnel with the next lane's pair (4 * a16 bits)
+                    uint32_t H, L, bad4;
+                    fast_pack4(v, H, L, bad4);
+                    const uint64_t b4 = ballot(bad4 != 0) & (~0ull >> (64 - nch));
+                    const uint64_t X = ((uint64_t)H << 32) | L, Xn = ((uint64_t)wave_shl1(H) << 32) | wave_shl1(L);
+                    const uint64_t W = a16 ? (X << (4 * a16)) | (Xn >> (64 - 4 * a16)) : X;
+                    done = fast_canonw<4, HASH, false>(a, lut, hc, rec, off, n, (uint32_t)(W >> 32), (uint32_t)W, b4 != 0);
+                } else {
+                    done = fast_canon<HASH, AUX>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
+                }
             }
             if (!done) defer_record(a, blk_count, block, rec);       // (no alphabet flag: the edge chunks hold neighbours' bytes too)
         }

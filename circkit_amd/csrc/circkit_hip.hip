@@ -257,11 +257,16 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 // at once (4-5 us instead of the ~40 us a full-size idle grid costs) and take the whole batch when the expectation was
 // wrong.  Two instantiations because the loop over virtual workgroups costs the hot path scalar registers (measured:
 // +2 % on the headline with one kernel for both).
-template <class StreamC, bool HASH, bool AUX, bool PERSIST>
+// ALPHA (ROWS = 1, no index / strand outputs): the build for batches with MODE_ALPHA -- records with N or '-' take the
+// 4-bit register routine inside the staged loop.  The builds without it answer for every other batch, MODE_ALPHA or not.
+template <class StreamC, bool HASH, bool AUX, bool PERSIST, bool ALPHA = false>
 __global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
                                                                                                              uint32_t host_mode, uint32_t nvb)
 {
-    if ((batch_mode(mode, host_mode) & 3) != (uint32_t)StreamC::ROWS) return;    // the other build (or none) has this batch
+    const uint32_t bm = batch_mode(mode, host_mode);
+    if ((bm & 3) != (uint32_t)StreamC::ROWS) return;                             // the other build (or none) has this batch
+    constexpr bool HAS_ALPHA_TWIN = StreamC::ROWS == 1 && !AUX;
+    if (HAS_ALPHA_TWIN && ((bm & MODE_ALPHA) != 0) != ALPHA) return;
     constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && StreamC::RPW == 1 && StreamC::GROUP == 16;
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<16>() : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE
     if (!PERSIST) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
-        ck::canon_stream_wave_loop<StreamC, HASH, AUX, GH>(a, lut, lds, blk_count, blockIdx.x, gridDim.x, gh);
+        ck::canon_stream_wave_loop<StreamC, HASH, AUX, GH, ALPHA>(a, lut, lds, blk_count, blockIdx.x, gridDim.x, gh);
         __syncthreads();
         if (threadIdx.x == 0) a.defer_count[blockIdx.x] = *blk_count;
         return;
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE
     for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
-        ck::canon_stream_wave_loop<StreamC, HASH, AUX, GH>(a, lut, lds, blk_count, vb, nvb, gh);
+        ck::canon_stream_wave_loop<StreamC, HASH, AUX, GH, ALPHA>(a, lut, lds, blk_count, vb, nvb, gh);
         ck::vmem_wait<0>();                              // no DMA of this virtual workgroup may land in the next one's images
         __syncthreads();
         if (threadIdx.x == 0) a.defer_count[vb] = *blk_count;
@@ -646,25 +651,31 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const uint32_t expect = host_mode ? host_mode & 3 : ((seen & 3) ? seen & 3 : 1u);
         const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
         const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64);
+        // (rows, alphabet) builds: ROWS = 1 lean, ROWS = 1 with the 4-bit routine, ROWS = 2.  The host's answer launches
+        // exactly one; a device-side decision launches all three, full-size where the previous batch's mode says it will run
+        const uint32_t expect_alpha = host_mode ? host_mode & MODE_ALPHA : seen & MODE_ALPHA;
         for (uint32_t rows = 1; rows <= 2; ++rows) {
             if (host_mode && (host_mode & 3) != rows) continue;
-            const bool full = expect == rows;            // full-size grid, one workgroup per segment; else the small walking grid
-            const dim3 grid(full ? G : small);
-#define CK_LAUNCH_STREAM(CFG, H, A, BLK)                                                                                         \
-            do {                                                                                                                \
-                if (full) hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, false>), grid, BLK, 0, c->stream, a, counts, host_mode, G); \
-                else hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, true>), grid, BLK, 0, c->stream, a, counts, host_mode, G);       \
-            } while (0)
-            if (rows == 1) {
-                if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux);
-                else if (d_hash) CK_LAUNCH_STREAM(StreamC, true, false, block);
-                else CK_LAUNCH_STREAM(StreamC, false, false, block);
-            } else {
-                if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux);
-                else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block);
-                else CK_LAUNCH_STREAM(StreamC2, false, false, block);
-            }
+            for (uint32_t alpha = 0; alpha <= (rows == 1 && !aux ? 1u : 0u); ++alpha) {
+                if (host_mode && rows == 1 && !aux && ((host_mode & MODE_ALPHA) != 0) != (alpha != 0)) continue;
+                const bool full = expect == rows && (rows != 1 || aux || (expect_alpha != 0) == (alpha != 0));
+                const dim3 grid(full ? G : small);
+#define CK_LAUNCH_STREAM(CFG, H, A, BLK, AL)                                                                                         \
+                do {                                                                                                                \
+                    if (full) hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, false, AL>), grid, BLK, 0, c->stream, a, counts, host_mode, G); \
+                    else hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, true, AL>), grid, BLK, 0, c->stream, a, counts, host_mode, G);       \
+                } while (0)
+                if (rows == 1) {
+                    if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux, false);
+                    else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamC, true, false, block, true); else CK_LAUNCH_STREAM(StreamC, true, false, block, false); }
+                    else { if (alpha) CK_LAUNCH_STREAM(StreamC, false, false, block, true); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
+                } else {
+                    if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux, false);
+                    else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block, false);
+                    else CK_LAUNCH_STREAM(StreamC2, false, false, block, false);
+                }
 #undef CK_LAUNCH_STREAM
+            }
         }
     }
     unsigned nseg = G;              // segments / capacity of the list the next stage consumes

@@ -163,8 +163,10 @@ void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
     else if (L->a.out_hash) {
         // the 16-wave, one-word build finishes XXH3 per record group (same condition as canon_stream_kernel)
         constexpr bool GH = C::ROWS == 1 && C::RPW == 1 && C::GROUP == 16;
-        ck::canon_stream_wave_loop<C, true, false, GH>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
+        if (L->alpha && C::ROWS == 1) ck::canon_stream_wave_loop<C, true, false, GH, C::ROWS == 1>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
+        else ck::canon_stream_wave_loop<C, true, false, GH>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
     }
+    else if (L->alpha && C::ROWS == 1) ck::canon_stream_wave_loop<C, false, false, false, C::ROWS == 1>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
     else ck::canon_stream_wave_loop<C, false, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
 }
 // geometries the staged streaming kernel is exercised with (index = `staged` argument - 1)
@@ -223,6 +225,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a.status = &status; L.a.comp_lut = comp; L.a.flags = flags;
     L.a.defer_list = list_f.data(); L.a.defer_count = cnt_f.data(); L.a.out_seg_cap = cap;
     L.lds = lds.data(); L.lut = lut; L.lutn = lutn; L.nblocks = G;
+    L.alpha = alpha != 0;        // which builds of the streaming kernel and the rescue pass (launch_canon: MODE_ALPHA of the batch's mode)
     uint32_t total_f = 0, total_a = 0;
     for (uint32_t b = 0; b < G && !all_records; ++b) {
         uint32_t blk = 0;
