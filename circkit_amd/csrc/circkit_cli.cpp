@@ -26,6 +26,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <new>
 #include <mutex>
 #include <string>
@@ -380,6 +381,7 @@ Input open_input(const Options& o)
 // src/utils.rs:29-72: compression by extension with the reference's levels (gz 6, bz2 9, xz 6, zst 1)
 struct Output {
     FILE* f = nullptr;
+    bool regular = false;              // an uncompressed regular file we created: chunks are assembled in parallel and written with pwrite
     bool piped = false, zstd_child = false;
     pid_t zpid = -1;
     std::vector<char> buf;
@@ -395,7 +397,12 @@ Output open_output(const Options& o)
     const char* tool = ends(".gz") ? "gzip -6" : ends(".bz2") ? "bzip2 -9" : ends(".xz") ? "xz -6" : ends(".zst") ? "zstd -1 -q" : nullptr;
     FILE* probe = fopen(p.c_str(), "wb");
     if (!probe) die("Could not create output file " + p + ". Are you sure it's not actually a directory?");   // src/utils.rs:46-49
-    if (!tool) { out.f = probe; setvbuf(out.f, out.buf.data(), _IOFBF, out.buf.size()); return out; }
+    if (!tool) {
+        out.f = probe; setvbuf(out.f, out.buf.data(), _IOFBF, out.buf.size());
+        struct stat st;
+        out.regular = fstat(fileno(probe), &st) == 0 && S_ISREG(st.st_mode) && !getenv("CIRCKIT_CLI_WRITEV_OUTPUT");
+        return out;
+    }
     if (ends(".zst")) {                              // level 1 (src/utils.rs:58-60) through libzstd, no `zstd` binary needed
         const int wfd = dup(fileno(probe));
         const int pfd = wfd >= 0 ? spawn_zstd(wfd, true, 1, &out.zpid) : -1;
@@ -441,13 +448,13 @@ struct Busy {
     };
     double s() const { return ns.load() * 1e-9; }
 };
-Busy g_read, g_parse, g_gpu, g_write;
+Busy g_read, g_parse, g_gpu, g_write, g_emit, g_pwrite;
 
 // ---- the pipeline ------------------------------------------------------------------------------------------
 // reader -> parser pool -> GPU -> writer over a ring of chunk slots.  Mirrors seq_io's parallel_fasta shape
 // (one reader, `--threads` workers, results consumed in input order: src/canonicalize.rs:17-45) with the worker
 // closure replaced by "parse + normalize + pack" on the host and ONE GPU batch call per chunk.
-enum State { FREE, READ, PARSED, COMPUTED };
+enum State { FREE, READ, PARSED, COMPUTED, ASSEMBLED };
 
 struct Slot {
     State state = FREE;
@@ -460,6 +467,10 @@ struct Slot {
     ckhost::ByteBuf canon;
     std::vector<uint64_t> hash, first_seen;
     uint64_t base = 0;
+    // positioned output (regular output file): byte offset of every record inside the chunk's window of the file
+    std::vector<uint64_t> ooff;                 // n + 1; a dropped record (uniq) has size 0
+    std::vector<uint8_t> obuf;                  // the chunk's output text, assembled by the emit workers
+    std::atomic<int> emit_left{ 0 };            // emit jobs of this chunk still running
 };
 
 struct Pipeline {
@@ -572,14 +583,16 @@ int main(int argc, char** argv)
         if (opt.table.size() >= 4 && opt.table.compare(opt.table.size() - 4, 4, ".tsv") == 0) delim = '\t';   // src/utils.rs:77-80
     }
     circkit_ctx* ctx = nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
     const int rc = circkit_ctx_create(opt.device, &ctx);
+    const double init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (rc != CIRCKIT_OK) die(std::string("no usable MI355X GPU (device ") + std::to_string(opt.device) + "): " +
                                (ctx ? circkit_last_error(ctx) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
     const bool uniq = opt.cmd == "uniq";
     const bool want_bytes = !uniq || opt.canonicalize;
     int n_parsers = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();   // src/commands.rs:120-123
     if (n_parsers < 1) n_parsers = 1;
-    if (n_parsers > 16) n_parsers = 16;
+    if (n_parsers > 64) n_parsers = 64;          // (beyond that the six chunk slots in flight are the limit, not the threads)
     static Pipeline P;
 
     for (Slot& sl : P.slot) {
@@ -692,10 +705,12 @@ int main(int argc, char** argv)
         }
     });
 
-    // ---- stage 4: writer, in input order (this thread).  Records go out with writev straight from the chunk text
-    // (headers, raw sequences) and the pinned canonical buffer: no formatting copy.  (Positioned writes of a batch's
-    // byte ranges from several threads were tried for regular files and measured slower -- 1.86 s instead of 1.35 s
-    // for 5 GB on tmpfs: buffered writes to one inode serialise on its lock.)
+    // ---- stage 4: writer, in input order (this thread) + emit workers.
+    // Regular output file: the writer only lays the chunk out (a prefix sum of the record sizes), grows the file and maps
+    // the chunk's window; the emit workers copy headers and sequences into the mapping in parallel -- page-cache pages
+    // are allocated by whoever touches them, so this scales where write() calls from several threads serialise on the
+    // inode lock (tried: 1.86 s instead of 1.35 s for 5 GB on tmpfs).  Pipes, stdout and compressed output keep the
+    // single-threaded writev straight from the chunk text and the pinned canonical buffer.
     std::vector<std::string> ids;                     // uniq --table: id of every kept record ...
     std::vector<uint64_t> kept_slot;                  // ... found through global index -> slot in ids
     bool table_header = false;
@@ -717,6 +732,58 @@ int main(int argc, char** argv)
         }
         iov.clear();
     };
+    const bool mapped_out = out.regular;
+    const int n_emit = mapped_out ? (n_parsers > 1 ? n_parsers : 2) : 0;
+    struct EmitJob { long seq; uint64_t r0, r1; };
+    std::deque<EmitJob> jobs;
+    std::mutex jm;
+    std::condition_variable jcv;
+    bool jobs_done = false;
+    std::vector<std::thread> emitters;
+    for (int t = 0; t < n_emit; ++t)
+        emitters.emplace_back([&] {
+            for (;;) {
+                EmitJob j;
+                {
+                    std::unique_lock<std::mutex> g(jm);
+                    jcv.wait(g, [&] { return !jobs.empty() || jobs_done; });
+                    if (jobs.empty()) return;
+                    j = jobs.front(); jobs.pop_front();
+                }
+                Busy::Scope tb(g_emit);
+                Slot& s = P.slot[j.seq % Pipeline::K];
+                const ckhost::Batch& b = s.batch;
+                uint8_t* base = s.obuf.data();
+                for (uint64_t i = j.r0; i < j.r1; ++i) {
+                    if (s.ooff[i + 1] == s.ooff[i]) continue;                  // dropped by uniq
+                    uint8_t* d = base + s.ooff[i];
+                    const ckhost::Span h = b.head[i];
+                    *d++ = '>';
+                    memcpy(d, s.text + h.off, h.len); d += h.len;
+                    *d++ = '\n';
+                    if (want_bytes) { const size_t L = (size_t)(b.offsets[i + 1] - b.offsets[i]); memcpy(d, s.canon.data() + b.offsets[i], L); d += L; }
+                    else { memcpy(d, s.text + b.raw[i].off, b.raw[i].len); d += b.raw[i].len; }
+                    *d = '\n';
+                }
+                if (--s.emit_left == 0) P.set(j.seq, ASSEMBLED);          // the writer thread puts it into the file
+            }
+        });
+    // chunks go into the file in order, by this thread only: one stream of large write() calls is what the kernel's
+    // per-inode lock allows anyway (positioned writes from the workers themselves: 3.1 s of pwrite for 1.6 s of wall)
+    long next_write = 0;
+    auto write_chunk = [&](long wseq) {
+        if (!P.wait(wseq, ASSEMBLED)) return;
+        Busy::Scope tw(g_pwrite);
+        Slot& s = P.slot[wseq % Pipeline::K];
+        const uint64_t total = s.ooff[s.batch.n()];
+        for (uint64_t done = 0; done < total;) {
+            const ssize_t w = write(ofd, s.obuf.data() + done, (size_t)(total - done));
+            if (w < 0) { if (errno == EINTR) continue; die("failed to write output"); }
+            done += (uint64_t)w;
+        }
+        P.set(wseq, FREE);
+    };
+    uint64_t file_size = 0;
     for (long seq = 0; P.wait(seq, COMPUTED); ++seq) {
         Busy::Scope tb(g_write);
         Slot& s = P.slot[seq % Pipeline::K];
@@ -724,8 +791,11 @@ int main(int argc, char** argv)
         const uint8_t* text = s.text;
         const uint64_t n = b.n();
         if (uniq && table) kept_slot.resize(s.base + n, ~0ull);
+        if (mapped_out) s.ooff.resize(n + 1);
+        uint64_t at = 0;
         for (uint64_t i = 0; i < n; ++i) {
             const ckhost::Span h = b.head[i];
+            if (mapped_out) s.ooff[i] = at;
             if (uniq) {
                 const bool keep = s.first_seen[i] == s.base + i;
                 if (table) {
@@ -745,25 +815,47 @@ int main(int argc, char** argv)
                 if (!keep) continue;
             }
             // ">" head "\n" sequence "\n"  (src/canonicalize.rs:33-37, src/uniq.rs:50-61)
+            const size_t seq_len = want_bytes ? (size_t)(b.offsets[i + 1] - b.offsets[i]) : b.raw[i].len;
+            if (mapped_out) { at += h.len + seq_len + 3; continue; }
             iov.push_back({ (void*)&GT, 1 });
             if (h.len) iov.push_back({ (void*)(text + h.off), h.len });
             iov.push_back({ (void*)&NL, 1 });
-            if (want_bytes) { if (b.offsets[i + 1] > b.offsets[i]) iov.push_back({ (void*)(s.canon.data() + b.offsets[i]), (size_t)(b.offsets[i + 1] - b.offsets[i]) }); }
-            else if (b.raw[i].len) iov.push_back({ (void*)(text + b.raw[i].off), b.raw[i].len });
+            if (seq_len) iov.push_back({ (void*)(want_bytes ? s.canon.data() + b.offsets[i] : text + b.raw[i].off), seq_len });
             iov.push_back({ (void*)&NL, 1 });
         }
-        flush_iov();
-        P.set(seq, FREE);
+        if (!mapped_out) { flush_iov(); P.set(seq, FREE); continue; }
+        s.ooff[n] = at;
+        if (at == 0) { s.emit_left = 0; P.set(seq, ASSEMBLED); while (next_write + 1 <= seq) write_chunk(next_write++); continue; }
+        // the chunk's place in the file; the emit workers assemble its text and the last of them writes it
+        if (s.obuf.size() < at) s.obuf.resize(at + at / 8);
+        file_size += at;
+        const uint64_t parts = n < (uint64_t)n_emit * 64 ? 1 : (uint64_t)n_emit;
+        s.emit_left = (int)parts;
+        {
+            std::lock_guard<std::mutex> g(jm);
+            for (uint64_t k = 0; k < parts; ++k) jobs.push_back(EmitJob{ seq, n * k / parts, n * (k + 1) / parts });
+        }
+        jcv.notify_all();
+        while (next_write + 1 <= seq) write_chunk(next_write++);        // one chunk behind the one just handed out
     }
+    if (mapped_out) { long last; { std::lock_guard<std::mutex> g(P.m); last = P.n_chunks; } while (next_write < last) write_chunk(next_write++); }
+    { std::lock_guard<std::mutex> g(jm); jobs_done = true; }
+    jcv.notify_all();
+    for (auto& t : emitters) t.join();
     reader.join();
     for (auto& t : parsers) t.join();
     gpu.join();
     if (getenv("CIRCKIT_CLI_TIMING"))
-        fprintf(stderr, "busy: read %.3f s  parse+pack %.3f (sum over %d threads)  gpu %.3f  write %.3f\n", g_read.s(), g_parse.s(),
-                n_parsers, g_gpu.s(), g_write.s());
+        fprintf(stderr, "HIP / ctx start-up %.3f s, pipeline %.3f s;  busy: read %.3f s  parse+pack %.3f (sum over %d threads)  gpu %.3f  write/layout %.3f  emit %.3f (sum over %d threads)  file write %.3f\n",
+                init_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() - init_s,
+                g_read.s(), g_parse.s(), n_parsers, g_gpu.s(), g_write.s(), g_emit.s(), n_emit, g_pwrite.s());
     close_output(out);
     if (table) fclose(table);
     close_input(in);
+    // Everything is written and closed.  Tearing down 768 MB of pinned buffers, the input mapping and the HIP runtime
+    // takes another 0.3-0.6 s that produces nothing: leave it to the kernel (CIRCKIT_CLI_CLEAN_EXIT=1 keeps the orderly
+    // teardown, e.g. under a leak checker).
+    if (!getenv("CIRCKIT_CLI_CLEAN_EXIT")) { fflush(nullptr); _exit(0); }
     for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }   // pinned memory goes before the ctx
     circkit_ctx_destroy(ctx);
     return 0;

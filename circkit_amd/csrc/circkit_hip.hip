@@ -1089,6 +1089,9 @@ int circkit_xxh3_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint
     return CIRCKIT_OK;
 }
 
+#ifndef CK_UNIQ_BPC
+#define CK_UNIQ_BPC 8        // workgroups of 256 threads per CU for the table kernels (one key per thread and trip)
+#endif
 #ifndef CK_UNIQ_LOAD_PCT
 #define CK_UNIQ_LOAD_PCT 70       // circkit_uniq_reset sizes the table for at most this load with `expected_keys` distinct keys
 #endif
@@ -1136,10 +1139,10 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
     int rc = ensure_staging(c, 0, n);
     if (rc) return rc;
     CK_HIP(c, hipMemcpyAsync(c->d_hash, hash, n * 8, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const uint64_t*)c->d_hash, (const uint64_t*)nullptr, n, base_index,
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, (const uint64_t*)c->d_hash, (const uint64_t*)nullptr, n, base_index,
                        c->d_table, c->uniq_mask, c->d_counters + 4);
     uint64_t* d_fs = (uint64_t*)c->d_off;          // staging reuse: offsets buffer holds >= n + 1 u64
-    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const uint64_t*)c->d_hash, n, (const UniqSlot*)c->d_table,
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, (const uint64_t*)c->d_hash, n, (const UniqSlot*)c->d_table,
                        c->uniq_mask, d_fs, (uint8_t*)nullptr, (uint64_t)0);
     CK_HIP(c, hipGetLastError());
     CK_HIP(c, hipMemcpyAsync(first_seen, d_fs, n * 8, hipMemcpyDeviceToHost, c->stream));
@@ -1154,7 +1157,7 @@ int circkit_uniq_insert_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
     if (!c->d_table) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, (const uint64_t*)nullptr, n, base_index,
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, (const uint64_t*)nullptr, n, base_index,
                        c->d_table, c->uniq_mask, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     c->uniq_count += n;
@@ -1167,7 +1170,7 @@ int circkit_uniq_insert_pairs_device(circkit_ctx* c, const uint64_t* d_hash, con
     if (!c->d_table) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, d_index, n, (uint64_t)0, c->d_table,
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, d_index, n, (uint64_t)0, c->d_table,
                        c->uniq_mask, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     c->uniq_count += n;
@@ -1182,7 +1185,7 @@ int circkit_uniq_lookup_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
     if (!c->d_table) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen,
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen,
                        (uint8_t*)nullptr, (uint64_t)0);
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
@@ -1195,9 +1198,9 @@ int circkit_uniq_resolve_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t
     if (!c || (n && (!d_hash || !d_first_seen))) return CIRCKIT_ERR_INVALID_ARG;
     int rc = circkit_uniq_reset(c, n);
     if (rc || n == 0) return rc;
-    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, (const uint64_t*)nullptr, n, base_index,
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, (const uint64_t*)nullptr, n, base_index,
                        c->d_table, c->uniq_mask, c->d_counters + 4);
-    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen,
+    hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen,
                        d_keep, base_index);
     CK_HIP(c, hipGetLastError());
     c->uniq_count = n;

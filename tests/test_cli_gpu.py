@@ -161,9 +161,10 @@ def test_not_fasta_is_an_error(tmp_path):
 
 
 def test_large_output_file_vs_stream_vs_oracle(tmp_path):
-    """30k records (two line-wrapped, some with N, duplicates for uniq): a regular output file is written by several
-    threads with positioned writes, stdout by one ordered stream -- both must equal the record-loop restatement byte
-    for byte, for canonicalize and for both uniq modes; appending (`>>`) must append."""
+    """30k records (two line-wrapped, some with N, duplicates for uniq): a regular output file goes out as whole chunks
+    assembled by a pool of threads and written in order by one (circkit_cli.cpp, stage 4), stdout as one ordered writev
+    stream -- both must equal the record-loop restatement byte for byte, for canonicalize and for both uniq modes;
+    appending (`>>`) must append."""
     import numpy as np
     from oracle import oracle as O
     rng = np.random.default_rng(5)

@@ -17,7 +17,7 @@ write = vals["WRITE_SIZE"] * 1024
 json.dump({
     "workload": "canonicalize 10000000 x 1000",
     "kernel": kernel,
-    "source": "profiles/r01_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per launch)",
+    "source": "profiles/r02_pmc_counters.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per launch)",
     "fetch_bytes": fetch, "write_bytes": write, "traffic_bytes": fetch + write,
     "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE exact",
     "insts_valu_per_record": vals["SQ_INSTS_VALU"] / n, "insts_salu_per_record": vals["SQ_INSTS_SALU"] / n,

@@ -1,0 +1,22 @@
+#!/bin/bash
+# GPU box, repo root: regenerates the judged artefacts of round 2 under gpurun_out/refresh/ (copy them into profiles/).
+# One bench line + one rocprofv3 --kernel-trace --stats summary per workload, and the PMC passes of the headline.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/refresh
+mkdir -p $O
+cd $R
+run() {   # tag, bench args...
+  tag=$1; shift
+  python bench.py "$@" > $O/r02_bench_$tag.json 2> $O/r02_bench_$tag.err || { echo "bench $tag failed"; tail -3 $O/r02_bench_$tag.err; }
+  tools/prof_run.sh refresh_$tag "$@" > /dev/null 2>&1
+  cp gpurun_out/refresh_${tag}_kernel_stats.csv $O/r02_kernel_stats_$tag.csv
+}
+run canonicalize
+run uniq --workload uniq
+run mixed --workload mixed
+run canonicalize_n1pct --n-frac 0.01
+run mixed_n1pct --workload mixed --n-frac 0.01
+tools/pmc_run.sh refresh_pmc > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/refresh_pmc > $O/r02_pmc_counters.txt
+python tools/make_traffic.py $O/r02_pmc_counters.txt "StreamCfg<16, 2, 1, 1>, false, false, false, false" $O/traffic.json > /dev/null
+ls -la $O
