@@ -50,6 +50,12 @@ def main():
                     help="records timed on the host cores (rank 0, N=1); default: 100k records per usable core (~0.7 s)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--exchange", default="partition", choices=["partition", "allgather"], help="uniq at --gpus > 1")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams (each with its own ctx and output buffers) the steps are dealt to round-robin, so that the "
+                         "short kernels behind a batch's main kernel (rescue pass, LDS tiers, table) overlap the next batch's main "
+                         "kernel instead of running alone on the chip (measured: headline 3.71 -> 3.57 ms per step, mixed 2.36 -> 2.23); "
+                         "the default 1 = strictly one batch after the other, so that the per-step time IS the kernel chain's time "
+                         "and agrees with a rocprofv3 kernel trace of the same command")
     ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
                     help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
                          "strand duplicates, hash + first-seen); mixed = configs[3] (1M records, L ~ 1/L on [200, 20000])")
@@ -98,27 +104,42 @@ def main():
         # global record index keeps every rank's shard distinct: record g of the job = bases [g*L, (g+1)*L) of seed 42
         total = N * L
         d_bytes, d_off = W.fixed_length(ctx, dev, N, L, 42, rank * N)
-    d_out = torch.empty(total + 64, dtype=torch.uint8, device=dev)
     if args.n_frac > 0:
         W.sprinkle_n(d_bytes, total, args.n_frac, 46 + rank, dev)
-    d_hash = None
     if args.workload == "uniq":
         W.plant_duplicates(d_bytes, N, L, dev, 43 + rank, 44 + rank)          # config 3
-        d_hash = torch.empty(N, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    table = U.DeviceTable(ctx)
-    state = {}
+    # one lane per stream: its own ctx (lists, table), torch stream and output buffers; the input is shared
+    S = max(1, args.streams)
+    if use_dist and args.workload == "uniq":
+        S = 1                       # the exchange's collectives stay on one stream, in one order on every rank
+    lanes = []
+    for k in range(S):
+        c = ctx if k == 0 else circkit_amd.Context(local_rank)
+        st = stream if k == 0 else torch.cuda.Stream(device=dev)
+        c.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            lane = {"ctx": c, "stream": st, "out": torch.empty(total + 64, dtype=torch.uint8, device=dev),
+                    "hash": torch.empty(N, dtype=torch.int64, device=dev) if args.workload == "uniq" else None, "fs": None, "keep": None}
+            lane["table"] = U.DeviceTable(c)
+        lanes.append(lane)
+    d_out = lanes[0]["out"]
+    state = lanes[0]
+    counter = [0]
 
     def step():
-        if args.workload == "uniq":
-            # what `circkit uniq --canonicalize` computes per batch: canonical bytes + XXH3, then the first-seen
-            # resolution -- the ctx table on one GPU, the hash-range exchange over RCCL on several
-            ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out, out_xxh3=d_hash)
-            state["fs"], state["keep"] = U.first_seen(table, d_hash, base_index=rank * N, exchange=args.exchange,
-                                                      force_exchange=force_dist)
-        else:
-            ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out)
+        ln = lanes[counter[0] % S]
+        counter[0] += 1
+        with torch.cuda.stream(ln["stream"]):
+            if args.workload == "uniq":
+                # what `circkit uniq --canonicalize` computes per batch: canonical bytes + XXH3, then the first-seen
+                # resolution -- the ctx table on one GPU, the hash-range exchange over RCCL on several
+                ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"], out_xxh3=ln["hash"])
+                ln["fs"], ln["keep"] = U.first_seen(ln["table"], ln["hash"], base_index=rank * N, exchange=args.exchange,
+                                                    force_exchange=force_dist)
+            else:
+                ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"])
 
     for _ in range(args.warmup):
         step()
@@ -126,24 +147,30 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in lanes]
     t0 = time.perf_counter()
     ev0.record(stream)
+    for ln in lanes[1:]:
+        ln["stream"].wait_event(ev0)                    # every lane starts behind the start event
     for _ in range(args.steps):
         step()
-    ev1.record(stream)
+    for ln, e in zip(lanes, ev1):
+        e.record(ln["stream"])
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
-    unprocessed = ctx.batch_status()
-    if unprocessed:
-        raise SystemExit("%d records were not processed" % unprocessed)
+    kernel_ms = max(ev0.elapsed_time(e) for e in ev1) / args.steps      # HIP events on the launch streams
+    for ln in lanes:
+        unprocessed = ln["ctx"].batch_status()
+        if unprocessed:
+            raise SystemExit("%d records were not processed" % unprocessed)
     unique_global = None
     if args.workload == "uniq":
-        table.check()
+        for ln in lanes:
+            ln["table"].check()
         u = state["keep"].sum().to(torch.int64)
         if use_dist:
             dist.all_reduce(u)
@@ -192,7 +219,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "records_per_gpu": N, "records_total": world * N,
                        "record_len": L if args.workload != "mixed" else "200..20000 (mean %d)" % (total // N),
-                       "parallelism": par},
+                       "parallelism": par + ("; steps dealt round-robin to %d HIP streams (one ctx each)" % S if S > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
@@ -207,7 +234,8 @@ def main():
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
-    ctx.close()
+    for ln in lanes:
+        ln["ctx"].close()
 
 
 def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):

@@ -69,8 +69,10 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
 // ticket) takes all output segments with the WHOLE scratch -- by then nobody else uses it.  The hand-over of the
 // lists between workgroups follows the agent-scope release / acquire recipe (cdna_hip_programming.md, Guideline 16):
 // stores drained, release fence, ticket; the last arriver acquires before it reads.  a2 = the arguments of phase 2.
-__global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::CanonArgs a2, uint32_t* scratch, uint32_t* ticket, const uint32_t* giants)
+__global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::CanonArgs a2, uint32_t* scratch, uint32_t* ticket, const uint32_t* giants,
+                                                          const uint32_t* tiers_busy, uint32_t* hint_out)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *hint_out = *tiers_busy ? 2u : 1u;     // pinned host word: 1 = the tiers idled, 2 = they worked
     if (*giants == 0) return;           // nothing came out of the last LDS tier (every ordinary batch): the launch costs ~3 us, not ~12
     __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[256], last;
     ck::fast_lut_init(lut, threadIdx.x, 64);
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __res
 {
     __shared__ uint32_t blk[3];
     if (threadIdx.x < 3) blk[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 3) { counters[0] = 0; counters[3] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 3) { counters[0] = 0; counters[1] = 0; counters[3] = 0; }
     __syncthreads();
     const uint32_t shift = count_shift(n);
     const uint64_t ns = count_samples(n);
@@ -227,7 +229,8 @@ __device__ __forceinline__ uint32_t batch_mode(const uint32_t* __restrict__ mode
 // ALPHA: the build with the 4-bit register path and the prefetching loop, for batches whose mode carries MODE_ALPHA
 // (builds with index / strand outputs exist only as ALPHA = false: their N-bearing records take the LDS tiers).
 template <bool HASH, bool AUX, bool ALPHA>
-__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out)
+__global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out,
+                                                           uint32_t* tiers_busy)
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
@@ -238,13 +241,18 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
     ck::RescueState<HASH, AUX> st;
     if (HASH) st.hc = ck::fast_hash_const();
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
+    uint32_t passed_on = 0, walked = 0;          // (thread 0) records this workgroup hands to the tiers / segments it walked
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
         if (threadIdx.x == 0) seg_count = 0;
         __syncthreads();
         ck::canon_rescue_segment<HASH, AUX, ALPHA>(a, lut, st, &seg_count, sgm, wib, 4, all_records);
         __syncthreads();
-        if (threadIdx.x == 0) a.defer_count[sgm] = seg_count;
+        if (threadIdx.x == 0) { a.defer_count[sgm] = seg_count; passed_on += seg_count; ++walked; }
     }
+    // a hint for the NEXT batch's launch: do the LDS tiers have real work (more than one record per segment on
+    // average)?  Idle tiers are launched with small grids (they walk the segments): a full-size grid that finds every
+    // segment empty costs 12-17 us per tier.  Plain store, same value from whoever stores.
+    if (threadIdx.x == 0 && passed_on > walked) *tiers_busy = 1;
 }
 
 // GH: the fused XXH3 is finished per 16-record group by one wave (canon_fast.h group_hash_*): 18.2 KiB more LDS, which
@@ -472,6 +480,9 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #ifndef CK_TIER_BPC
 #define CK_TIER_BPC 128    // workgroups launched per CU by the LDS tiers at most (they walk the list segments); 128 = one per segment
 #endif
+#ifndef CK_TIER_BPC_IDLE
+#define CK_TIER_BPC_IDLE 8 // ...when the previous batch left them (next to) nothing to do
+#endif
 #ifndef CK_TIER_KEEP
 #define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
 #endif
@@ -693,15 +704,16 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
 #endif
         // both alphabets' builds unless the host has decided; the one the mode does not name returns at once
         const bool lean = !host_mode || !(host_mode & MODE_ALPHA), alpha = !host_mode || (host_mode & MODE_ALPHA);
-        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         else if (d_hash) {
-            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<true, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
-            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<true, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<true, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<true, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         } else {
-            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<false, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
-            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out);
+            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<false, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         }
     }
+    const bool tiers_idle = c->h_mode[1] == 1;       // the previous batch's tiers found (next to) nothing: small grids for this one
     for (int t = 0; t < N_TIERS; ++t) {
         const bool last = t == N_TIERS - 1;
         const unsigned spb = t <= CK_TIER_KEEP ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
@@ -714,7 +726,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.out_seg_cap = spb * seg_cap;
         a.slice_dw = TIER_DW[t];
         // `grid` virtual workgroups; launched: a few times what is resident at once (dispatch order balances the rest)
-        const unsigned launched = grid < (unsigned)N_CU * CK_TIER_BPC ? grid : (unsigned)N_CU * CK_TIER_BPC;
+        const unsigned bpc = tiers_idle ? CK_TIER_BPC_IDLE : CK_TIER_BPC;
+        const unsigned launched = grid < (unsigned)N_CU * bpc ? grid : (unsigned)N_CU * bpc;
         if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
         else hipLaunchKernelGGL(canon_kernel<1>, dim3(launched), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, last ? c->d_counters : (uint32_t*)nullptr);
         nseg = grid;
@@ -739,7 +752,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a2.in_nseg = w1; a2.in_seg_cap = spb1 * seg_cap; a2.segs_per_block = w1;
         a2.defer_list = nullptr; a2.defer_count = nullptr; a2.out_seg_cap = 0;
         a2.slice_dw = (uint32_t)(cap_dw < 0xFFFFFFFFull ? cap_dw : 0xFFFFFFFFull);
-        hipLaunchKernelGGL(canon_global_kernel, dim3(w1), dim3(64), 0, c->stream, a, a2, c->d_gscratch, c->d_counters + 2, (const uint32_t*)c->d_counters);
+        hipLaunchKernelGGL(canon_global_kernel, dim3(w1), dim3(64), 0, c->stream, a, a2, c->d_gscratch, c->d_counters + 2, (const uint32_t*)c->d_counters,
+                           (const uint32_t*)(c->d_counters + 1), c->d_mode + 1);
     }
     if (d_hash) {
         hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed);
@@ -888,7 +902,7 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     CK_HIP(c, hipEventCreate(&c->ev0));
     CK_HIP(c, hipEventCreate(&c->ev1));
     CK_HIP(c, hipHostMalloc((void**)&c->h_mode, 64, hipHostMallocMapped));
-    *c->h_mode = 0;
+    c->h_mode[0] = 0; c->h_mode[1] = 0;
     CK_HIP(c, hipHostGetDevicePointer((void**)&c->d_mode, (void*)c->h_mode, 0));
     CK_HIP(c, hipMalloc(&c->d_comp, 256));
     CK_HIP(c, hipMalloc(&c->d_counters, 16 * sizeof(uint32_t)));
