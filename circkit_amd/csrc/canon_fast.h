@@ -215,8 +215,8 @@ CK_DEV void fast_shape(FastShape& sh, uint32_t n)
 
 // HASH = false compiles the fused XXH3 out; AUX = false compiles out what only some callers ask for (rotation index
 // and strand outputs, forward-only mode).
-// gh_slot != nullptr: the hash is finished by the workgroup's merger (group_hash_put), else here (fast_hash).
-template <bool HASH, bool AUX>
+// GH: the hash is finished by the workgroup's merger (group_hash_put into gh_slot), else here (fast_hash).
+template <bool HASH, bool AUX, bool GH = false>
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
                        uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr)
 {
@@ -267,7 +267,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
             const u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
             if (store && valid) store16(a.out_bytes + off + o, cell);
             if (hash) {
-                if (gh_slot) {
+                if constexpr (GH) {
                     group_hash_put(gh_slot, hc.k0, hc.k1, cell, E, idx, n);
                 } else {
                     const uint64_t h = fast_hash(hc, lut, cell, E, idx, n);

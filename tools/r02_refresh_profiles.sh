@@ -20,3 +20,9 @@ tools/pmc_run.sh refresh_pmc > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/refresh_pmc > $O/r02_pmc_counters.txt
 python tools/make_traffic.py $O/r02_pmc_counters.txt "StreamCfg<16, 2, 1, 1>, false, false, false, false" $O/traffic.json > /dev/null
 ls -la $O
+# the same three workloads with the steps dealt to three ctx/stream lanes (bench lines only: overlapping launches make
+# per-kernel durations of a trace meaningless)
+python bench.py --streams 3 --no-cpu > $O/r02_bench_canonicalize_streams3.json 2>/dev/null
+python bench.py --workload uniq --streams 3 --no-cpu > $O/r02_bench_uniq_streams3.json 2>/dev/null
+python bench.py --workload mixed --streams 3 --no-cpu > $O/r02_bench_mixed_streams3.json 2>/dev/null
+ls $O | wc -l
