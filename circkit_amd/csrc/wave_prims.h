@@ -289,6 +289,12 @@ CK_DEV void lds_store16(uint32_t* p, u32x4 v)      // 16-byte-aligned LDS addres
     *reinterpret_cast<v4*>(p) = t;
 }
 
+// two 16-bit unsigned minima at once (v_pk_min_u16)
+CK_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
 #define CK_CONST __device__ __constant__
 CK_DEV uint64_t mulhi64(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 

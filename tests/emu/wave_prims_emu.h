@@ -143,6 +143,11 @@ CK_DEV void sload_group(const uint64_t* p, const uint64_t* q, uint64_t& s, uint6
 {
     s = p[0]; e = p[SPAN]; o0 = q[0]; o1 = q[1]; o2 = q[2];
 }
+CK_DEV uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = (a & 0xFFFF) < (b & 0xFFFF) ? (a & 0xFFFF) : (b & 0xFFFF), hi = (a >> 16) < (b >> 16) ? (a >> 16) : (b >> 16);
+    return (hi << 16) | lo;
+}
 #define CK_CONST static const
 CK_DEV uint64_t mulhi64(uint64_t a, uint64_t b) { return (uint64_t)(((__uint128_t)a * b) >> 64); }
 CK_DEV uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
