@@ -623,3 +623,17 @@ def test_device_api_batch_full_of_long_records(ctx, O):
         if rep:
             assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
     ctx.use_own_stream()
+
+
+@pytest.mark.parametrize("profile,count", [("nrich", "100000"), ("longn", "20000")])
+def test_randomized_n_paths(profile, count):
+    """tools/gpu_fuzz.py with N / '-' in most records: "nrich" makes the batch's mode carry MODE_ALPHA (4-bit register
+    routine in the streaming kernel and in the rescue pass), "longn" drives the 2-bit-with-N-mask mode of the LDS tiers
+    (records of 1..9 kb with up to 30 N) and its fallbacks to the 4-bit mode."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), "79", count, profile], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout

@@ -3,7 +3,9 @@ index builds on a subsample).  Mixtures aimed at the streaming kernel's rare pat
 16-mers, tandem repeats, reverse-complement palindromes (equal minimal keys on both strands), records around the
 48 / 240 / 1008 limits, N / '-' sprinkled in, lengths 0..1300.
 usage: python tools/gpu_fuzz.py [seed] [records] [profile]   (profile "long": most records 1009..2032 bases -- the
-two-words-per-lane build of the streaming kernel)"""
+two-words-per-lane build of the streaming kernel; "nrich": half of the records carry N / '-' -- the batch's mode gets
+MODE_ALPHA: 4-bit register routine in the streaming kernel and the rescue pass; "longn": records of 1..9 kb with a few
+N -- the 2-bit-with-N-mask mode of the LDS tiers and its fallbacks)"""
 import os
 import sys
 import time
@@ -33,7 +35,9 @@ seqs = []
 t0 = time.time()
 for i in range(count):
     k = rng.integers(0, 100)
-    if profile == "long" and k < 85:
+    if profile == "longn":
+        L = int(rng.integers(1009, 9000)) if k < 90 else int(rng.integers(48, 1009))
+    elif profile == "long" and k < 85:
         L = int(rng.integers(1009, 2033)) if k < 60 else int(rng.choice([1009, 1010, 1023, 1024, 1025, 1039, 1040, 1041, 1164, 1500, 1679, 2015, 2016, 2017, 2031, 2032, 2033, 2047, 2048, 2049]))
     elif k < 30: L = 1000
     elif k < 60: L = int(rng.integers(48, 1009))
@@ -60,8 +64,8 @@ for i in range(count):
             p = int(rng.integers(1, 17))
             s = np.resize(s[:p], L).copy()
             s[-1] = ord("T") if s[-1] != ord("T") else ord("G")
-        elif m < 25:                               # a few N / '-' somewhere
-            for _ in range(int(rng.integers(1, 4))):
+        elif m < (25 if profile in ("short", "long") else 75):        # a few N / '-' somewhere
+            for _ in range(int(rng.integers(1, 4 if profile != "longn" else 30))):
                 s[int(rng.integers(0, len(s)))] = ord("N") if rng.random() < 0.7 else ord("-")
         elif m < 27:
             s[:] = ord("A")
