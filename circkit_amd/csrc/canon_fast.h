@@ -251,7 +251,10 @@ CK_DEV void fast_shape(FastShape& sh, uint32_t n)
 // HASH = false compiles the fused XXH3 out; AUX = false compiles out what only some callers ask for (rotation index
 // and strand outputs, forward-only mode).
 // GH: the hash is finished by the workgroup's merger (group_hash_put into gh_slot), else here (fast_hash).
-template <bool HASH, bool AUX, bool GH = false>
+// K16: two-level scan (8-symbol prefixes first).  The staged streaming kernel is bound by vector-instruction issue and
+// gains from it; the latency-bound rescue pass lost a third of its speed to it (mixed lengths: 225 -> 330 us) and keeps
+// the one-level scan.
+template <bool HASH, bool AUX, bool GH = false, bool K16 = false>
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
                        uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr)
 {
@@ -281,9 +284,9 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
     // Level 1: 8-symbol prefixes (word_min_key16).  They decide the strand and the rotation whenever the two strands'
     // minimal prefixes differ and the winner's is owned by one position -- the minimal keys ARE the first symbols of the
     // two minimal rotations (lib/src/canonicalize.rs:58-62: forward only if strictly smaller).
-    bool fwd, tie, uE, uF = true;
-    uint32_t idx, iF;
-    {
+    bool fwd = true, tie = true, uE = false, uF = true;
+    uint32_t idx = 0, iF = 0;
+    if constexpr (K16) {
         uint32_t mF = valid ? word_min_key16(F, Fn) : 0xFFFFu, mC = valid ? word_min_key16(C, Cn) : 0xFFFFu;
         uint32_t MF, MC;
         wave_min2_u32(mF, mC, MF, MC);

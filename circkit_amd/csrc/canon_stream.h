@@ -171,7 +171,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                     const uint64_t W = a16 ? (X << (4 * a16)) | (Xn >> (64 - 4 * a16)) : X;
                     done = fast_canonw<4, HASH, false>(a, lut, hc, rec, off, n, (uint32_t)(W >> 32), (uint32_t)W, b4 != 0);
                 } else {
-                    done = fast_canon<HASH, AUX, GH>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
+                    done = fast_canon<HASH, AUX, GH, true>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
                 }
             }
             if (!done) defer_record(a, blk_count, block, rec);       // (no alphabet flag: the edge chunks hold neighbours' bytes too)
