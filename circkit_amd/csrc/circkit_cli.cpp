@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <errno.h>
 #include <math.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -567,6 +568,25 @@ int run_host_edit(const Options& opt, Input& in, Output& out)
     return 0;
 }
 
+// The reference's default is num_cpus::get() (src/commands.rs:120-123): the CPUs this process may run on, and under a
+// cgroup CPU quota no more than the quota allows -- a container that shows 256 CPUs but grants 16 runs 64 threads slower
+// than 16 (measured on the GPU boxes: 2.5-3.2 against 3.8 M records/s).
+int default_threads()
+{
+    long n = (long)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long quota = (atol(q) + period - 1) / period;
+            if (quota >= 1 && quota < n) n = quota;
+        }
+        fclose(f);
+    }
+    return n < 1 ? 1 : (int)n;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -590,7 +610,7 @@ int main(int argc, char** argv)
                                (ctx ? circkit_last_error(ctx) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
     const bool uniq = opt.cmd == "uniq";
     const bool want_bytes = !uniq || opt.canonicalize;
-    int n_parsers = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();   // src/commands.rs:120-123
+    int n_parsers = opt.threads > 0 ? opt.threads : default_threads();   // src/commands.rs:120-123
     if (n_parsers < 1) n_parsers = 1;
     if (n_parsers > 64) n_parsers = 64;          // (beyond that the six chunk slots in flight are the limit, not the threads)
     static Pipeline P;
@@ -769,7 +789,9 @@ int main(int argc, char** argv)
             }
         });
     // chunks go into the file in order, by this thread only: one stream of large write() calls is what the kernel's
-    // per-inode lock allows anyway (positioned writes from the workers themselves: 3.1 s of pwrite for 1.6 s of wall)
+    // per-inode lock allows anyway (positioned writes from the workers themselves: 3.1 s of pwrite for 1.6 s of wall;
+    // workers filling shared mappings of the file, pages allocated by faults or by madvise(MADV_POPULATE_WRITE): the
+    // allocations contend inside the kernel, 14-260 s of summed worker time for the same 1.0 s of pipeline at best)
     long next_write = 0;
     auto write_chunk = [&](long wseq) {
         if (!P.wait(wseq, ASSEMBLED)) return;
