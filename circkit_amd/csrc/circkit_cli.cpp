@@ -591,6 +591,7 @@ int default_threads()
 
 int main(int argc, char** argv)
 {
+    const auto t_main = std::chrono::steady_clock::now();
     const Options opt = parse_args(argc, argv);
     Input in = open_input(opt);
     Output out = open_output(opt);
@@ -785,7 +786,16 @@ int main(int argc, char** argv)
                     else { memcpy(d, s.text + b.raw[i].off, b.raw[i].len); d += b.raw[i].len; }
                     *d = '\n';
                 }
-                if (--s.emit_left == 0) P.set(j.seq, ASSEMBLED);          // the writer thread puts it into the file
+                if (--s.emit_left == 0) {
+                    // The chunk's text is not needed again: drop its pages from the input mapping here, chunk by chunk and
+                    // next to the other workers, instead of all 1.2M of a 5 GB file at exit (0.4 s of a 1.6 s run went
+                    // into that teardown).  The page cache keeps the data; only this process's page tables shrink.
+                    if (in.map && s.text >= in.map && s.text < in.map + in.map_len) {
+                        const uintptr_t p0 = ((uintptr_t)s.text + 4095) & ~(uintptr_t)4095, p1 = (uintptr_t)(s.text + s.len) & ~(uintptr_t)4095;
+                        if (p1 > p0) (void)madvise((void*)p0, p1 - p0, MADV_DONTNEED);
+                    }
+                    P.set(j.seq, ASSEMBLED);          // the writer thread puts it into the file
+                }
             }
         });
     // chunks go into the file in order, by this thread only: one stream of large write() calls is what the kernel's
@@ -868,7 +878,8 @@ int main(int argc, char** argv)
     for (auto& t : parsers) t.join();
     gpu.join();
     if (getenv("CIRCKIT_CLI_TIMING"))
-        fprintf(stderr, "HIP / ctx start-up %.3f s, pipeline %.3f s;  busy: read %.3f s  parse+pack %.3f (sum over %d threads)  gpu %.3f  write/layout %.3f  emit %.3f (sum over %d threads)  file write %.3f\n",
+        fprintf(stderr, "main() to here %.3f s;  HIP / ctx start-up %.3f s, pipeline %.3f s;  busy: read %.3f s  parse+pack %.3f (sum over %d threads)  gpu %.3f  write/layout %.3f  emit %.3f (sum over %d threads)  file write %.3f\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(),
                 init_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() - init_s,
                 g_read.s(), g_parse.s(), n_parsers, g_gpu.s(), g_write.s(), g_emit.s(), n_emit, g_pwrite.s());
     close_output(out);
