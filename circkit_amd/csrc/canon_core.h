@@ -386,8 +386,12 @@ CK_DEV bool locate_unique(WordAt word_at, uint32_t n, const ScanMin& sm, uint32_
 // ------------------------------------------------------------------------------------------------
 // smallest index of the lexicographically minimal rotation + the rotation period
 // ------------------------------------------------------------------------------------------------
+// bm_ok: the LDS slice has room for the candidate bitmask.  It is only needed on a tie of the minimal key, which ordinary
+// DNA of these lengths practically never has -- so the 2-bit tiers admit records by the strand alone (a 20 kb record:
+// 4.9 KiB instead of 7.4) and a record that does tie without room answers idx = NO_ROOM and moves on to the next tier.
+constexpr uint32_t NO_ROOM = 0xFFFFFFFFu;
 template <int BITS, bool RCV>
-CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
+CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm, bool bm_ok = true)
 {
     constexpr uint32_t S = 32 / BITS;
     const uint32_t lane = lane_id();
@@ -399,6 +403,7 @@ CK_DEV RotResult find_min_rot(const uint32_t* E, uint32_t n, uint32_t* bm)
         uint32_t pos = 0;
         if (locate_unique<BITS>(word_at, n, sm, pos)) return RotResult{ pos, n };
     }
+    if (!bm_ok) return RotResult{ NO_ROOM, n };
 
     // general path.  1: candidate bitmask = positions whose key equals M
     const uint32_t nbm = (n + 31) / 32;
@@ -504,9 +509,12 @@ CK_DEV uint32_t need_dw(uint32_t n)
     constexpr uint32_t S = 32 / BITS;
     return (BITS == 2 ? 1 : 2) * ((n + S - 1) / S + 2) + (n + 31) / 32 + 1;      // one stored strand in 2-bit mode, two otherwise
 }
+CK_DEV uint32_t need_dw_strand2(uint32_t n) { return (n + 15) / 16 + 2; }         // 2-bit mode without the candidate bitmask
 
+// 0: done; 1: a byte outside the mode's alphabet; 2 (2-bit mode only): the minimal key ties and the slice has no room for
+// the candidate bitmask
 template <int BITS>
-CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* src, uint64_t off, uint32_t n,
+CK_DEV int canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* src, uint64_t off, uint32_t n,
                               uint32_t* lds, const uint32_t* lut)
 {
     constexpr uint32_t S = 32 / BITS;
@@ -518,13 +526,16 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
     if (BITS == 8) {
         build_bytes(src, n, Ef, Er, a.comp_lut);
     } else {
-        if (!build_packed<BITS>(src, n, Ef, Er)) return false;
+        if (!build_packed<BITS>(src, n, Ef, Er)) return 1;
     }
-    const RotResult f = find_min_rot<BITS, false>(Ef, n, bm);
+    const bool bm_ok = BITS != 2 || need_dw<2>(n) <= a.slice_dw;
+    const RotResult f = find_min_rot<BITS, false>(Ef, n, bm, bm_ok);
+    if (f.idx == NO_ROOM) return 2;
     RotResult r{ 0, n };
     bool fwd = true;
     if (!(a.flags & CK_FLAG_FWD_ONLY)) {
-        r = find_min_rot<BITS, RCV>(Er, n, bm);
+        r = find_min_rot<BITS, RCV>(Er, n, bm, bm_ok);
+        if (r.idx == NO_ROOM) return 2;
         // lib/src/canonicalize.rs:58-62: forward only if strictly smaller
         fwd = lcp_rot<BITS, false, RCV>(Ef, Er, f.idx, r.idx, n).cmp < 0;
     }
@@ -538,7 +549,7 @@ CK_DEV bool canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* s
         if (a.out_index) a.out_index[rec] = fwd ? f.idx : (r.idx + f.idx) % f.period;
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
-    return true;
+    return 0;
 }
 
 
@@ -694,14 +705,16 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
     }
     if (n >= 48) {
         if (!not_acgt) {
-            if (need_dw<2>(n) > a.slice_dw) return false;
+            if (need_dw_strand2(n) > a.slice_dw) return false;
             // a look at the first KiB before the strand is built: with N sprinkled in at 1 %, that is where a long
             // record shows it (its bytes are in the cache for the builder afterwards)
             uint32_t miss = 0;
             if (16 * lane_id() + 16 <= n) (void)fast_pack(load16(src + 16 * lane_id()), miss);
             not_acgt = ballot(miss != 0) != 0;
             if (!not_acgt) {
-                if (canon_record_mode<2>(a, rec, src, off, n, lds, lut)) return true;
+                const int r2 = canon_record_mode<2>(a, rec, src, off, n, lds, lut);
+                if (r2 == 0) return true;
+                if (r2 == 2) return false;          // pure ACGT, tied minimal key, no room for the bitmask: next tier
                 not_acgt = true;
             }
         }
@@ -715,7 +728,7 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
             wave_sync();            // every lane has read the strands before the next mode overwrites them
         }
         if (need_dw<4>(n) > a.slice_dw) return false;
-        if (canon_record_mode<4>(a, rec, src, off, n, lds, lut)) return true;
+        if (canon_record_mode<4>(a, rec, src, off, n, lds, lut) == 0) return true;
     }
     if (need_dw<8>(n) > a.slice_dw) return false;
     canon_record_mode<8>(a, rec, src, off, n, lds, lut);
@@ -733,6 +746,8 @@ CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block
 
 // loop of one wave (wave `wib` of `wpb` in workgroup `block` of `nblocks`) over its share of the work.
 // (Loading the next record's list entry and offsets one record ahead was tried and measured: no gain.)
+// (Handing a segment's entries out dynamically -- an LDS counter per workgroup instead of the fixed stride, so that no wave
+// waits for the one that drew the long records -- was tried on BASELINE config 4: 2.29 -> 2.41 ms.)
 CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, uint32_t* blk_count, uint32_t block,
                             uint32_t nblocks, uint32_t wib, uint32_t wpb, const uint32_t* lutn = nullptr)
 {

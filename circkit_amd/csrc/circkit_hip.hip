@@ -60,7 +60,7 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
     }
 }
 
-// The end of the line: records no LDS tier can hold (2-bit beyond ~260 kb).  Same code, one wave per record, with the
+// The end of the line: records no LDS tier can hold (2-bit beyond ~640 kb).  Same code, one wave per record, with the
 // packed strands and the candidate bitmask in a slice of GLOBAL scratch instead of LDS.  The lanes of one wavefront
 // hand data to each other through that memory; wave_sync()'s wavefront-scope fences are what the AMDGPU memory model
 // asks for there (one wave, one L1, in-order vector memory), so canon_core.h runs unchanged.
@@ -467,13 +467,15 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS tiers of the general kernel (dwords per wave; + 260 dwords per workgroup: deferral counter and decode table).
-//   A: 4 waves x 4 KiB per workgroup (9 workgroups per CU)    2-bit records up to ~6.5 kb
-//   B1: 1 wave x 9 KiB (16 per CU)                            2-bit up to ~14.7 kb
-//   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~21 kb: covers BASELINE config 4's 20 kb tail
-//   C: 1 wave x 39 KiB (4 per CU)                             2-bit up to ~63 kb, byte-mode up to ~18 kb
-//   D: 1 wave x 158 KiB (the whole CU)                        2-bit up to ~258 kb, byte-mode up to ~76 kb
-//   beyond: canon_global_kernel, the same code over slices of a global-memory scratch (two more stages of every batch)
+// LDS tiers of the general kernel (dwords per wave; + 516 dwords per workgroup: deferral counter, decode table, N patch
+// table).  A 2-bit record needs its ONE stored strand, n / 16 + 2 dwords (+ n / 32 for the candidate bitmask only if the
+// minimal key ties); with a few N two strands; 4-bit and byte mode two strands + the bitmask.
+//   A: 4 waves x 5 KiB per workgroup (7 workgroups per CU)    2-bit records up to ~20.4 kb: all of BASELINE config 4
+//   B1: 1 wave x 7.4 KiB (17 per CU)                          2-bit up to ~30 kb, with a few N up to ~15 kb
+//   B2: 1 wave x 13 KiB (10 per CU)                           2-bit up to ~53 kb, with a few N up to ~26 kb
+//   C: 1 wave x 39 KiB (3 per CU)                             2-bit up to ~160 kb, byte-mode up to ~17 kb
+//   D: 1 wave x 157 KiB (the whole CU)                        2-bit up to ~640 kb, 4-bit up to ~100 kb, byte-mode up to ~70 kb
+//   beyond: canon_global_kernel, the same code over slices of a global-memory scratch (one more launch of every batch)
 #ifndef CK_RESCUE_BPC
 #define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
 #endif
@@ -486,11 +488,16 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #ifndef CK_TIER_KEEP
 #define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
 #endif
+// A 2-bit record is admitted by its one stored strand alone, (n + 15) / 16 + 2 dwords (the candidate bitmask is only needed
+// on a tie of the minimal key; a record that ties without room for it moves on).  Tier A: 5 KiB per wave = records up to
+// 20.4 kb -- all of BASELINE config 4 in the four-wave tier, 7 workgroups = 28 waves per CU by LDS and by VGPRs alike
+// (measured on config 4, one box: A = 4 KiB + B1 = 7.4 KiB with the bitmask counted in 2.41 ms, without it 2.30,
+// A = 2.5 KiB + B1 = 5 KiB 2.41, A = 5 KiB 2.20, A = 5.5 KiB 2.47).
 #ifndef CK_TIER_A
-#define CK_TIER_A 1023
+#define CK_TIER_A 1280
 #endif
 #ifndef CK_TIER_B1
-#define CK_TIER_B1 1900     // 2-bit records up to ~20.2 kb (one stored strand): all of BASELINE config 4 behind tier A
+#define CK_TIER_B1 1900     // 2-bit records up to ~30 kb, with a few N (two strands) up to ~15 kb
 #endif
 #ifndef CK_TIER_B2
 #define CK_TIER_B2 3324
@@ -734,10 +741,11 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         seg_cap = spb * seg_cap;
     }
     {
-        // Records no LDS tier can hold (2-bit beyond ~258 kb, byte-mode beyond ~76 kb): the same code, one wave per
+        // Records no LDS tier can hold (2-bit beyond ~640 kb, byte-mode beyond ~70 kb): the same code, one wave per
         // record, with a slice of the global scratch in place of the LDS slice -- one more launch.  Phase 1: up to 64
-        // waves x 4 MiB (2-bit records up to ~6.7 Mb); phase 2 (the last workgroup to finish): one wave with the whole
-        // scratch (256 MiB by default: 2-bit up to ~430 Mb, bytes up to ~126 MB; circkit_ctx_set_long_record_scratch).
+        // waves x 4 MiB (2-bit records up to ~16.7 Mb); phase 2 (the last workgroup to finish): one wave with the whole
+        // scratch (256 MiB by default: 2-bit up to ~1 Gb -- ~700 Mb if the minimal key ties --, bytes up to ~126 MB;
+        // circkit_ctx_set_long_record_scratch).
         // Beyond: counted in status[0].
         const uint64_t cap_dw = c->cap_gscratch / 4;
         const uint64_t slice1 = cap_dw < GSLICE1_DW ? cap_dw : GSLICE1_DW;

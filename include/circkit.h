@@ -73,9 +73,9 @@ int circkit_ctx_last_kernel_ms(circkit_ctx* ctx, float* ms);
  * d_bytes / d_out_bytes, and offsets[0] need not be 0.
  * The call enqueues EVERYTHING the batch needs: once the stream has run past it the outputs are complete, whichever
  * way the caller synchronises, and the next batch may be enqueued straight behind it.  Records too long for the
- * on-chip tiers (pure ACGT beyond ~260 kb, other alphabets beyond ~76-130 kb) are taken by the batch's last two
+ * on-chip tiers (pure ACGT beyond ~640 kb, other alphabets beyond ~70-320 kb) are taken by the batch's last two
  * kernels in a ctx-owned global-memory scratch (256 MiB unless circkit_ctx_set_long_record_scratch says otherwise:
- * pure ACGT up to ~430 Mb, arbitrary bytes up to ~126 MB); a record beyond that is left untouched and counted by
+ * pure ACGT up to ~1 Gb, arbitrary bytes up to ~126 MB); a record beyond that is left untouched and counted by
  * circkit_ctx_batch_status. */
 int circkit_canonicalize_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                                       uint64_t n_records, uint8_t* d_out_bytes, uint32_t* d_out_index,
@@ -94,8 +94,9 @@ int circkit_xxh3_batch_device(circkit_ctx* ctx, const uint8_t* d_bytes, const ui
  * CIRCKIT_ERR_TOO_LONG. */
 int circkit_ctx_batch_status(circkit_ctx* ctx, uint32_t* n_unprocessed);
 /* Size in bytes of the global-memory scratch the device entry points give to records beyond the on-chip tiers (a
- * record of n symbols needs ~0.63 n bytes when pure ACGT, ~1.13 n for {-,A,C,G,N,T}, ~2.13 n otherwise).  The
- * host-buffer entry points see the lengths and grow the scratch by themselves.  Synchronizes. */
+ * record of n symbols needs ~0.25 n bytes when pure ACGT -- 0.38 n if its minimal 16-mer repeats --, ~1.13 n for
+ * {-,A,C,G,N,T}, ~2.13 n otherwise).  The host-buffer entry points see the lengths and grow the scratch by
+ * themselves.  Synchronizes. */
 int circkit_ctx_set_long_record_scratch(circkit_ctx* ctx, uint64_t bytes);
 /* Which build of the streaming kernel the most recent device batch selected, from that batch's own lengths: 1 = one
  * packed word per lane (records up to 1008 b), 2 = two words (a quarter or more of the records in 1009..2032 b),

@@ -52,8 +52,20 @@ def test_long_records_multi_row():
 
 def test_deferral_to_bigger_tier():
     seqs = seqsets.random_mixed(30, 20, 100, 3000)
-    n = check(seqs, slice_dw=200)
+    n = check(seqs, slice_dw=120)                  # the 2-bit strand of a record up to 1888 bases fits (no bitmask needed)
     assert 0 < n < len(seqs)
+
+
+def test_tied_minimal_key_without_room_for_the_bitmask_moves_on():
+    """The 2-bit tiers admit a record by its strand alone; only a tie of the minimal key needs the candidate bitmask.
+    Tandem repeats (every key ties) of 1600 bases: the strand needs 102 dwords, strand + bitmask 153.  A 120-dword
+    slice defers exactly them -- untouched -- and finishes the random records around them; 160 dwords take all."""
+    rng = np.random.default_rng(33)
+    rep = [bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8)) * (1600 // k) for k in (5, 8, 20, 32)]
+    rnd = seqsets.random_mixed(34, 6, 1500, 1800)
+    seqs = [rnd[0], rep[0], rnd[1], rep[1], rep[2], rnd[2], rnd[3], rep[3], rnd[4], rnd[5]]
+    assert check(seqs, slice_dw=120) == len(rep)
+    assert check(seqs, slice_dw=160) == 0
 
 
 def test_wave_count_independent():

@@ -139,9 +139,9 @@ def test_lds_tiers_long_records(ctx, O):
 
 
 def test_records_beyond_the_lds_tiers(ctx, O):
-    """Records no LDS tier can hold (2-bit beyond ~260 kb, with N beyond ~130 kb, arbitrary bytes beyond ~76 kb) are
-    taken by the batch's last two kernels in global scratch, same code: host API, all outputs; mixed into a batch of
-    ordinary records."""
+    """Records no LDS tier can hold (2-bit beyond ~640 kb -- ~420 kb when the minimal key ties and the candidate bitmask
+    is needed --, 4-bit beyond ~100 kb, arbitrary bytes beyond ~70 kb) are taken by the batch's last kernel in global
+    scratch, same code: host API, all outputs; mixed into a batch of ordinary records."""
     from tests import seqsets
     rng = np.random.default_rng(3)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -150,7 +150,8 @@ def test_records_beyond_the_lds_tiers(ctx, O):
            np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 200_000)].tobytes(),
            rng.integers(1, 128, 100_000).astype(np.uint8).tobytes(),      # arbitrary ASCII: byte mode
            (acgt[rng.integers(0, 4, 977)].tobytes() * 400)[:390_000],     # long tandem repeat: the duel path, period 977
-           b"A" * 280_000]
+           b"A" * 280_000,
+           (acgt[rng.integers(0, 4, 1013)].tobytes() * 600)[:600_000]]    # its strand fits tier D, strand + bitmask does not: moves on to the scratch
     seqs = seqsets.random_mixed(81, 30, 48, 1008) + big[:3] + seqsets.random_mixed(82, 10, 2000, 9000) + big[3:] + [b"ACGT"]
     _check(ctx, O, seqs)
 
@@ -223,10 +224,10 @@ def test_long_record_scratch_limit_is_reported(O):
     import circkit_amd
     from tests import seqsets
     c = circkit_amd.Context(0)
-    c.set_long_record_scratch(1 << 20)               # 1 MiB: pure-ACGT records up to ~2.7 Mb
+    c.set_long_record_scratch(1 << 20)               # 1 MiB: pure-ACGT records up to ~4.19 Mb
     rng = np.random.default_rng(6)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    seqs = seqsets.random_mixed(87, 20, 100, 1008) + [acgt[rng.integers(0, 4, 1_000_000)].tobytes(), acgt[rng.integers(0, 4, 3_500_000)].tobytes()]
+    seqs = seqsets.random_mixed(87, 20, 100, 1008) + [acgt[rng.integers(0, 4, 1_000_000)].tobytes(), acgt[rng.integers(0, 4, 4_500_000)].tobytes()]
     data, offs = seqsets.pack(seqs)
     dev = torch.device("cuda", 0)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
