@@ -273,6 +273,19 @@ CK_DEV void rescue_one(const CanonArgs& a, const uint32_t* lut, RescueState<HASH
     }
     if (!done) defer_record(a, seg_count, seg_index, rec, not_acgt);
 }
+// one pure-ACGT record of 48..1008 bases through the register routine, 16 bytes per lane straight from memory
+template <bool HASH, bool AUX>
+CK_DEV bool rescue_direct(const CanonArgs& a, const uint32_t* lut, RescueState<HASH, AUX>& st, uint32_t rec, uint64_t off, uint64_t len, bool& not_acgt)
+{
+    if (len > FAST_MAX_N || !fast_eligible((uint32_t)len)) return false;
+    const uint32_t n = (uint32_t)len, nwf = n >> 4, t = lane_id();
+    uint32_t miss;
+    uint32_t F = fast_pack(load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t)), miss);
+    F <<= t >= nwf ? ((16 - (n & 15)) & 15) * 2 : 0;
+    const uint64_t bad = ballot(miss != 0);
+    not_acgt = bad != 0;
+    return fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F, bad);
+}
 template <bool HASH, bool AUX, bool ALPHA>
 CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, RescueState<HASH, AUX>& st, uint32_t* seg_count, uint32_t seg_index,
                                  uint32_t wib, uint32_t wpb, bool all_records)
@@ -288,17 +301,8 @@ CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, Rescue
         for (uint32_t i = wib; i < count; i += wpb) {
             const uint32_t rec = all_records ? (uint32_t)first + i : seg[i] & ENTRY_REC;
             const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
-            bool done = false, not_acgt = false;
-            if (len <= FAST_MAX_N && fast_eligible((uint32_t)len)) {
-                const uint32_t n = (uint32_t)len, nwf = n >> 4;
-                uint32_t miss;
-                uint32_t F = fast_pack(load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t)), miss);
-                F <<= t >= nwf ? ((16 - (n & 15)) & 15) * 2 : 0;
-                const uint64_t bad = ballot(miss != 0);
-                not_acgt = bad != 0;
-                done = fast_canon<HASH, AUX>(a, lut, st.hc, st.shape, rec, off, n, F, bad);
-            }
-            if (!done) defer_record(a, seg_count, seg_index, rec, not_acgt);
+            bool not_acgt = false;
+            if (!rescue_direct<HASH, AUX>(a, lut, st, rec, off, len, not_acgt)) defer_record(a, seg_count, seg_index, rec, not_acgt);
         }
         return;
     }

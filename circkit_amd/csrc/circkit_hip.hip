@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
+    if (!AUX && !ALPHA && (mode & 3) == 3) return;                       // ... or canon_mixed_kernel
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
     const bool all_records = (mode & 3) == 3;                           // the streaming kernel stood this batch out
     __shared__ uint32_t lut[ck::FAST_LUT_DW], seg_count;
@@ -252,6 +253,49 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
     // a hint for the NEXT batch's launch: do the LDS tiers have real work (more than one record per segment on
     // average)?  Idle tiers are launched with small grids (they walk the segments): a full-size grid that finds every
     // segment empty costs 12-17 us per tier.  Plain store, same value from whoever stores.
+    if (threadIdx.x == 0 && passed_on > walked) *tiers_busy = 1;
+}
+
+// Batches of mixed lengths (mode 3: the streaming kernel stands them out), pure ACGT: ONE kernel walks all records, four
+// waves per workgroup with a tier-A slice each.  A record of 48..1008 bases takes the register routine straight from
+// memory (what the rescue pass did for such a batch), every other record the general LDS routine (what tier A did with the
+// rescue pass's list), so the latency-bound short records and the bandwidth-bound long ones share the CUs instead of
+// following each other in two launches with a list in between.  Segment s = records [s * in_seg_cap, (s + 1) * in_seg_cap);
+// what the slice cannot hold goes to segment s of the list tier A consumes.
+template <bool HASH>
+__global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out,
+                                                                      uint32_t* tiers_busy)
+{
+    const uint32_t mode = batch_mode(mode_word, host_mode);
+    if ((mode & 3) != 3 || (mode & MODE_ALPHA)) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* blk_count = lds + 4 * a.slice_dw;
+    uint32_t* lut = blk_count + 4;
+    uint32_t* lutn = lut + ck::FAST_LUT_DW;
+    ck::fast_lut_init(lut, threadIdx.x, 256);
+    ck::fast_lutn_init(lutn, threadIdx.x, 256);
+    ck::RescueState<HASH, false> st;
+    if (HASH) st.hc = ck::fast_hash_const();
+    const uint32_t wib = ck::uniform(threadIdx.x >> 6);
+    uint32_t* slice = lds + wib * a.slice_dw;
+    uint32_t passed_on = 0, walked = 0;
+    for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
+        if (threadIdx.x == 0) *blk_count = 0;
+        __syncthreads();
+        const uint64_t first = (uint64_t)sgm * a.in_seg_cap;
+        const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.in_seg_cap ? a.n_records - first : a.in_seg_cap));
+        for (uint32_t i = wib; i < count; i += 4) {
+            const uint32_t rec = (uint32_t)first + i;
+            const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
+            bool not_acgt = false;
+            if (ck::rescue_direct<HASH, false>(a, lut, st, rec, off, len, not_acgt)) continue;
+            if (!ck::canon_record(a, rec, slice, lut, lutn, not_acgt)) ck::defer_record(a, blk_count, sgm, rec, not_acgt);
+            ck::wave_sync();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
+    }
     if (threadIdx.x == 0 && passed_on > walked) *tiers_busy = 1;
 }
 
@@ -710,7 +754,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         uint32_t* mode_out = c->d_mode;               // straight into pinned host memory: no copy-back, no event
 #endif
         // both alphabets' builds unless the host has decided; the one the mode does not name returns at once
-        const bool lean = !host_mode || !(host_mode & MODE_ALPHA), alpha = !host_mode || (host_mode & MODE_ALPHA);
+        const bool mixed_has_it = host_mode && !aux && (host_mode & 3) == 3 && !(host_mode & MODE_ALPHA);
+        const bool lean = (!host_mode || !(host_mode & MODE_ALPHA)) && !mixed_has_it, alpha = !host_mode || (host_mode & MODE_ALPHA);
         if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         else if (d_hash) {
             if (lean) hipLaunchKernelGGL((canon_rescue_kernel<true, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
@@ -719,6 +764,21 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             if (lean) hipLaunchKernelGGL((canon_rescue_kernel<false, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
             if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         }
+    }
+    if (!aux && (!host_mode || ((host_mode & 3) == 3 && !(host_mode & MODE_ALPHA)))) {
+        // mode 3, pure ACGT: canon_mixed_kernel takes every record (the rescue pass above stood out); same lists, same
+        // segments.  One workgroup per segment when the previous batch was such a batch, else a small walking grid.
+        const bool was_mixed = host_mode ? true : ((*c->h_mode & 3) == 3 && !(*c->h_mode & MODE_ALPHA));
+        const unsigned grid = was_mixed ? nseg : (nseg < (unsigned)N_CU * CK_RESCUE_BPC ? nseg : (unsigned)N_CU * CK_RESCUE_BPC);
+        a.slice_dw = TIER_DW[0];
+        const size_t shmem = (4 * TIER_DW[0] + TIER_EXTRA_DW) * 4;
+#ifdef CK_NO_PINNED_MODE
+        uint32_t* mode_out = c->d_counters + 6;
+#else
+        uint32_t* mode_out = c->d_mode;
+#endif
+        if (d_hash) hipLaunchKernelGGL(canon_mixed_kernel<true>, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+        else hipLaunchKernelGGL(canon_mixed_kernel<false>, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
     }
     const bool tiers_idle = c->h_mode[1] == 1;       // the previous batch's tiers found (next to) nothing: small grids for this one
     for (int t = 0; t < N_TIERS; ++t) {
