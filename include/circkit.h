@@ -146,7 +146,9 @@ int circkit_uniq_insert_pairs_device(circkit_ctx* ctx, const uint64_t* d_hash, c
 int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen);
 /* One shard in one call: reset (sized for n keys), insert with indices base_index .. base_index + n - 1, lookup, and
  * d_keep[i] (nullable, uint8) = 1 iff d_first_seen[i] == base_index + i -- the reference's per-record decision "emit,
- * or write a table row" (src/uniq.rs:47-62). */
+ * or write a table row" (src/uniq.rs:47-62).  n < 2^32 - 1.  The table's contents are private to the call (it keeps
+ * shard-local indices in a layout of its own): circkit_uniq_insert_* / _lookup_device refuse to touch it until the next
+ * circkit_uniq_reset. */
 int circkit_uniq_resolve_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t base_index,
                                 uint64_t* d_first_seen, uint8_t* d_keep);
 /* reset / insert / lookup / resolve only enqueue work.  circkit_uniq_status waits for it and fails with CIRCKIT_ERR_OOM when
