@@ -556,17 +556,20 @@ CK_DEV int canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* sr
 // ------------------------------------------------------------------------------------------------
 // 2-bit mode for records with a FEW N ("2N"): the reference sorts N like any other byte (between G and T,
 // lib/src/canonicalize.rs:50-53), but one N in 20 kb should not push the record into the 4-bit mode at 2-3x the cost.
-// N is packed as G and remembered in a second strand of masks (0b11 at every N).  Every key that holds an N is then
-// SMALLER than or equal to its true value (G < N), and every other key is exact, so:
+// N is packed as G -- so the reverse-strand view shows a C there -- and remembered in a bitmask, one bit per symbol.
+// On either strand every key that holds an N is then SMALLER than its true value (C < G < N) and every other key is
+// exact, so:
 //   * if the smaller of the two strands' minimal keys is owned by exactly one position whose 16-symbol window is
 //     N-free, that position is the true minimal rotation of the true winning strand (any window with an N has a true
 //     key above its packed key >= that minimum; the other strand's true minimum is above its packed minimum);
 //   * anything else -- equal minimal keys, a tie, an N inside the winning window -- is left to the 4-bit mode.
-// The reverse-strand view complements G to C where the forward strand held an N; the mask strand, read through the
-// same window and bit-reversed, turns that C back into G.  Output bytes are patched from 'G' to 'N' by a second table.
+// The scans never look at the mask (the 2-bit scan as it is); it is read once at the winning position and along the
+// output, where the decoded 'G' (forward) or 'C' (reverse) is patched to 'N' through a 16-entry table.
+// LDS: the strand + n / 32 + 2 dwords (the first version kept a second STRAND of masks and corrected the reverse view
+// with it in every scan step: twice the LDS, so that a 20 kb record with one N fell to the 13 KiB tier).
 // ------------------------------------------------------------------------------------------------
-// 16 ASCII bytes -> 16 two-bit codes with N -> G, the N mask (0b11 per N), miss != 0 iff a byte is outside ACGTN
-CK_DEV uint32_t fast_pack_n(u32x4 v, uint32_t& nmask, uint32_t& miss)
+// 16 ASCII bytes -> 16 two-bit codes with N -> G, the N mask (bit 15 = first symbol), miss != 0 iff a byte is outside ACGTN
+CK_DEV uint32_t fast_pack_n(u32x4 v, uint32_t& nmask16, uint32_t& miss)
 {
     const uint32_t d[4] = { v.x, v.y, v.z, v.w };
     uint32_t u[4], m[4];
@@ -576,65 +579,93 @@ CK_DEV uint32_t fast_pack_n(u32x4 v, uint32_t& nmask, uint32_t& miss)
         const uint32_t sel = (d[k] >> 1) & HASH_MASK;                       // A0 C1 T2 G3 ... N7
         miss = sad_u8(perm(0x4E000000u, CHK2_LO, sel), d[k], miss);
         u[k] = udot4(perm(0x02000000u, 0x02030100u, sel), 0x01041040u, 0u);
-        m[k] = udot4((sel >> 2) & 0x01010101u, 0x030C30C0u, 0u);            // selector bit 2: N (everything else up there is refused)
+        m[k] = udot4((sel >> 2) & 0x01010101u, 0x01020408u, 0u);            // selector bit 2: N (everything else up there is refused)
     }
-    nmask = (((m[0] << 8 | m[1]) << 8 | m[2]) << 8) | m[3];
+    nmask16 = (((m[0] << 4 | m[1]) << 4 | m[2]) << 4) | m[3];
     return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
 }
-// 256-entry LDS table: mask byte (4 symbols, 0b11 per N) -> the XOR that turns a decoded 'G' into 'N' in those bytes
+// 16-entry LDS table: 4 mask bits (bit 3 = first symbol) -> 0x01 in the byte of every N (times 'G' ^ 'N' or 'C' ^ 'N')
 CK_DEV void fast_lutn_init(uint32_t* lutn, uint32_t tid, uint32_t nthreads)
 {
-    for (uint32_t x = tid; x < 256; x += nthreads) {
+    for (uint32_t x = tid; x < 16; x += nthreads) {
         uint32_t o = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o |= (((x >> (6 - 2 * k)) & 1u) * 0x09u) << (8 * k);     // 'G' ^ 'N' = 0x09
+        for (int k = 0; k < 4; ++k) o |= ((x >> (3 - k)) & 1u) << (8 * k);
         lutn[x] = o;
     }
 }
-// forward words + mask words (+ the periodic extension of both); returns false when a byte is outside ACGTN
-CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Nm)
+constexpr uint32_t FAST_LUTN_DW = 16;
+// the mask bits of the 16 symbols at cyclic position p (0 <= p < 2n), first symbol in bit 15
+CK_DEV uint32_t nmask16_at(const uint32_t* Nb, uint32_t p, uint32_t n)
+{
+    p = p >= n ? p - n : p;
+    return funnel(Nb[p >> 5], Nb[(p >> 5) + 1], p & 31) >> 16;
+}
+// forward words (+ periodic extension) and the N bitmask (32 symbols per dword, first symbol in the top bit, extended
+// periodically by 32 symbols or more); returns false when a byte is outside ACGTN
+CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Nb)
 {
     const uint32_t lane = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
     uint32_t bad = 0;
     constexpr int U = CK_BUILD_ROWS;
-    for (uint32_t w0 = lane; w0 < nwv; w0 += 64 * U) {
+    for (uint32_t w0 = 0; w0 < nwv; w0 += 64 * U) {             // (wave-uniform trip count: the mask halves meet by DPP)
         u32x4 vf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t w = w0 + 64 * u;
+            const uint32_t w = w0 + lane + 64 * u;
             if (w < nwv) vf[u] = load16(src + (w >= nwf ? n - 16 : w * 16));        // the tail word reads the record's last 16 bytes
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t w = w0 + 64 * u;
+            const uint32_t w = w0 + lane + 64 * u;
+            uint32_t nm = 0;
             if (w < nwv) {
-                const uint32_t sh = w >= nwf ? (16 - r) * 2 : 0u;
-                uint32_t nm, miss;
-                Ef[w] = fast_pack_n(vf[u], nm, miss) << sh;
-                Nm[w] = nm << sh;
+                const uint32_t sh = w >= nwf ? 16 - r : 0u;                         // tail: the last r symbols move to the top
+                uint32_t miss;
+                Ef[w] = fast_pack_n(vf[u], nm, miss) << (2 * sh);
+                nm = (nm << sh) & 0xFFFFu;
                 bad |= miss;
             }
+            const uint32_t nx = wave_shl1(nm);                                      // the odd neighbour's 16 bits (0 past the record)
+            if (!(lane & 1) && w < nwv) Nb[w >> 1] = (nm << 16) | nx;
         }
     }
     const bool ok = ballot(bad != 0) == 0;
     wave_sync();
     if (lane < 3) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            uint32_t* E = s ? Nm : Ef;
-            if (lane == 0) {
-                if (r) E[nwf] = E[nwf] | (E[0] >> (r * 2));
-            } else {
-                const uint32_t e = lane - 1;
-                E[nwv + e] = r ? funnel(E[e], E[e + 1], (16 - r) * 2) : E[e];
-            }
+        if (lane == 0) {
+            if (r) Ef[nwf] = Ef[nwf] | (Ef[0] >> (r * 2));
+        } else {
+            const uint32_t e = lane - 1;
+            Ef[nwv + e] = r ? funnel(Ef[e], Ef[e + 1], (16 - r) * 2) : Ef[e];
         }
+    } else if (lane == 3) {
+        // mask: symbols n .. n + 32 (or more) repeat symbols 0 ..; the bits past n in dword n / 32 are zero so far
+        const uint32_t q = n & 31, nd = n >> 5, a0 = Nb[0];
+        const uint32_t x = q ? (Nb[nd] | (a0 >> q)) : a0;
+        const uint32_t a1 = nd == 1 ? x : Nb[1];
+        Nb[nd] = x;
+        Nb[nd + 1] = q ? ((a0 << (32 - q)) | (a1 >> q)) : a1;
     }
     wave_sync();
     return ok;
 }
-CK_DEV uint32_t need_dw_2n(uint32_t n) { return 2 * ((n + 15) / 16 + 2) + 1; }
+CK_DEV uint32_t need_dw_2n(uint32_t n) { return (n + 15) / 16 + 2 + (n >> 5) + 2; }
+
+// how many of the strand's n positions start a key that agrees with K in its first 32 - sh bits (simple loop: rare path)
+template <class WordAt>
+CK_DEV uint32_t count_prefix2(WordAt word_at, uint32_t n, uint32_t K, uint32_t sh)
+{
+    const uint32_t nwv = (n + 15) / 16;
+    uint32_t cnt = 0;
+    for (uint32_t w = lane_id(); w < nwv; w += 64) {
+        const uint32_t cur = word_at(w * 16), nxt = word_at((w + 1) * 16);
+        const uint32_t valid = n - w * 16 < 16 ? n - w * 16 : 16;
+        for (uint32_t b = 0; b < valid; ++b) cnt += ((funnel(cur, nxt, 2 * b) ^ K) >> sh) == 0 ? 1u : 0u;
+    }
+    return (uint32_t)wave_sum_u64(cnt);
+}
 
 // 0: done; 1: leave it to the 4-bit mode (a byte outside ACGTN, or one of the cases listed above)
 CK_DEV int canon_record_mode2n(const CanonArgs& a, uint64_t rec, const uint8_t* src, uint64_t off, uint32_t n, uint32_t* lds,
@@ -642,15 +673,15 @@ CK_DEV int canon_record_mode2n(const CanonArgs& a, uint64_t rec, const uint8_t* 
 {
     const uint32_t nwv = (n + 15) / 16;
     uint32_t* Ef = lds;
-    uint32_t* Nm = lds + (nwv + 2);
-    if (!build_packed2n(src, n, Ef, Nm)) return 1;
+    uint32_t* Nb = lds + (nwv + 2);
+    if (!build_packed2n(src, n, Ef, Nb)) return 1;
     const auto mirror = [&](uint32_t p) {                   // start of the forward window behind reverse-strand position p
         p = p >= n ? p - n : p;
         const int32_t s0 = (int32_t)n - 16 - (int32_t)p;
         return (uint32_t)(s0 + ((s0 >> 31) & (int32_t)n));
     };
     const auto fwd_at = [&](uint32_t p) { return sym_word<2>(Ef, p, n); };
-    const auto rc_at = [&](uint32_t p) { const uint32_t s = mirror(p); return rc_word<2>(sym_word<2>(Ef, s, n)) ^ bitrev(sym_word<2>(Nm, s, n)); };
+    const auto rc_at = [&](uint32_t p) { return rc_word<2>(sym_word<2>(Ef, mirror(p), n)); };
     const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
     const ScanMin sf = dense_scan<2>(fwd_at, n);
     ScanMin sc = sf;
@@ -662,18 +693,39 @@ CK_DEV int canon_record_mode2n(const CanonArgs& a, uint64_t rec, const uint8_t* 
     uint32_t pos = 0, fpos = 0;
     const bool uq = fwd ? locate_unique<2>(fwd_at, n, sf, pos) : locate_unique<2>(rc_at, n, sc, pos);
     if (!uq) return 1;
-    if (sym_word<2>(Nm, fwd ? pos : mirror(pos), n) != 0) return 1;            // an N inside the winning window
+    {
+        // An N inside the winning window, first at offset j.  Every other key is above K in the packed order; one that
+        // differs from K before offset j stays above it in the true order (K's symbols there are exact, the other key's can
+        // only grow).  Forward winner (N packed as G): a key that shares the first j symbols and differs at offset j holds
+        // a T there, and T > N -- so the position still wins if nothing else, on either strand, shares its first j + 1
+        // packed symbols.  Reverse winner (its N shows as C): a sharer of the first j symbols may hold a true G at offset
+        // j, below N -- so nothing else may share the first j symbols.  With 1 % N one window in ten holds an N, mostly
+        // far enough back for the prefix to be unique: without this a tenth of the long records went on to the 4-bit
+        // mode, which for 20 kb means the 39 KiB tier at four waves per CU.
+        const uint32_t mw = fwd ? nmask16_at(Nb, pos, n) : bitrev(nmask16_at(Nb, mirror(pos), n)) >> 16;
+        if (mw != 0) {
+            const uint32_t j = (uint32_t)clz32(mw) - 16, plen = fwd ? j + 1 : j;
+            if (plen == 0) return 1;
+            const uint32_t sh = 32 - 2 * plen, K = fwd ? sf.M : sc.M;
+            uint32_t c = count_prefix2(fwd_at, n, K, sh);
+            if (!fwd_only) c += count_prefix2(rc_at, n, K, sh);
+            if (c != 1) return 1;
+        }
+    }
     if (!fwd && a.out_index) {                                                  // the reference-visible index counts from the forward minimum
-        if (!locate_unique<2>(fwd_at, n, sf, fpos) || sym_word<2>(Nm, fpos, n) != 0) return 1;
+        if (!locate_unique<2>(fwd_at, n, sf, fpos) || nmask16_at(Nb, fpos, n) != 0) return 1;
     }
     if (a.out_bytes) {
         uint8_t* out = a.out_bytes + off;
+        const uint32_t fix = fwd ? 0x09u : 0x0Du;                               // 'G' ^ 'N', 'C' ^ 'N'
         for (uint32_t w = lane_id(); w < nwv; w += 64) {
             const uint32_t p = pos + w * 16;
             const uint32_t v = fwd ? fwd_at(p) : rc_at(p);
-            const uint32_t m = fwd ? sym_word<2>(Nm, p, n) : bitrev(sym_word<2>(Nm, mirror(p), n));
+            const uint32_t m = fwd ? nmask16_at(Nb, p, n) : bitrev(nmask16_at(Nb, mirror(p), n)) >> 16;
             u32x4 o = fast_decode(lut, v);
-            o.x ^= lutn[m >> 24]; o.y ^= lutn[(m >> 16) & 0xFF]; o.z ^= lutn[(m >> 8) & 0xFF]; o.w ^= lutn[m & 0xFF];
+            if (m) {
+                o.x ^= lutn[m >> 12] * fix; o.y ^= lutn[(m >> 8) & 15] * fix; o.z ^= lutn[(m >> 4) & 15] * fix; o.w ^= lutn[m & 15] * fix;
+            }
             const uint32_t left = n - w * 16;
             store_bytes(out + w * 16, o, left < 16 ? left : 16);
         }

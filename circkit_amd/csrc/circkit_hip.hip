@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::C
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *hint_out = *tiers_busy ? 2u : 1u;     // pinned host word: 1 = the tiers idled, 2 = they worked
     if (*giants == 0) return;           // nothing came out of the last LDS tier (every ordinary batch): the launch costs ~3 us, not ~12
-    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[256], last;
+    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[ck::FAST_LUTN_DW], last;
     ck::fast_lut_init(lut, threadIdx.x, 64);
     ck::fast_lutn_init(lutn, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::C
 // one record in global scratch (the host API's single-record calls)
 __global__ __launch_bounds__(64) void canon_global_one_kernel(ck::CanonArgs a, uint32_t* scratch)
 {
-    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[256];
+    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[ck::FAST_LUTN_DW];
     ck::fast_lut_init(lut, threadIdx.x, 64);
     ck::fast_lutn_init(lutn, threadIdx.x, 64);
     if (threadIdx.x == 0) blk_count = 0;
@@ -580,12 +580,13 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS tiers of the general kernel (dwords per wave; + 516 dwords per workgroup: deferral counter, decode table, N patch
+// LDS tiers of the general kernel (dwords per wave; + 276 dwords per workgroup: deferral counter, decode table, N patch
 // table).  A 2-bit record needs its ONE stored strand, n / 16 + 2 dwords (+ n / 32 for the candidate bitmask only if the
-// minimal key ties); with a few N two strands; 4-bit and byte mode two strands + the bitmask.
+// minimal key ties); with a few N the strand + n / 32 of N bitmask; 4-bit and byte mode two strands + the bitmask.
 //   A: 4 waves x 5 KiB per workgroup (7 workgroups per CU)    2-bit records up to ~20.4 kb: all of BASELINE config 4
-//   B1: 1 wave x 7.4 KiB (17 per CU)                          2-bit up to ~30 kb, with a few N up to ~15 kb
-//   B2: 1 wave x 13 KiB (10 per CU)                           2-bit up to ~53 kb, with a few N up to ~26 kb
+//   A (cont.)                                                 ... with a few N up to ~13.6 kb
+//   B1: 1 wave x 7.4 KiB (18 per CU)                          2-bit up to ~30 kb, with a few N up to ~20.2 kb
+//   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~53 kb, with a few N up to ~35 kb
 //   C: 1 wave x 39 KiB (3 per CU)                             2-bit up to ~160 kb, byte-mode up to ~17 kb
 //   D: 1 wave x 157 KiB (the whole CU)                        2-bit up to ~640 kb, 4-bit up to ~100 kb, byte-mode up to ~70 kb
 //   beyond: canon_global_kernel, the same code over slices of a global-memory scratch (one more launch of every batch)
@@ -610,14 +611,14 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #define CK_TIER_A 1280
 #endif
 #ifndef CK_TIER_B1
-#define CK_TIER_B1 1900     // 2-bit records up to ~30 kb, with a few N (two strands) up to ~15 kb
+#define CK_TIER_B1 1900     // 2-bit records up to ~30 kb, with a few N (strand + bitmask) up to ~20.2 kb
 #endif
 #ifndef CK_TIER_B2
 #define CK_TIER_B2 3324
 #endif
 constexpr int N_TIERS = 5;
 constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40188u : 31996u };     // + 260 dwords of counter and decode table per workgroup
-constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW + 256;        // counter, decode table, N patch table
+constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW + ck::FAST_LUTN_DW;        // counter, decode table, N patch table
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
 constexpr int N_CU = 256;
 

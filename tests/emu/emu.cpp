@@ -214,7 +214,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[ck::FAST_LUT_DW];
     ck::fast_lut_init(lut, 0, 1);
-    uint32_t lutn[256];
+    uint32_t lutn[ck::FAST_LUTN_DW];
     ck::fast_lutn_init(lutn, 0, 1);
     Launch L;
     L.a = ck::CanonArgs{};

@@ -300,3 +300,72 @@ def test_two_bit_mode_with_n_mask_in_the_lds_tiers():
                 assert out[a:b].tobytes() == want[i][0], (i, len(s), s[:30])
             if want_aux:
                 assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, len(s))
+
+
+def test_two_bit_mode_with_n_bitmask_is_the_mode_that_runs():
+    """A 400-dword slice holds the 4-bit strands of records up to ~1.4 kb only, the 2-bit strand + N bitmask up to
+    ~4.2 kb: records of 1.5..4 kb with a few N that come out right there took canon_record_mode2n.  Lengths around the
+    multiples of 16 and 32 (tail word, bitmask extension), both strands winning, rotation index and strand checked."""
+    rng = np.random.default_rng(1300)
+    seqs = []
+    for L in list(range(1536, 1536 + 34)) + [2048, 2049, 2063, 2064, 3000, 3999, 4000]:
+        s = bytearray(seqsets.random_mixed(1301 + L, 1, L, L)[0])
+        for p in rng.integers(0, L, size=max(1, L // 150)):
+            s[int(p)] = ord("N")
+        seqs.append(bytes(s))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=400, n_waves=8, alpha=False)
+    done = 0
+    for i, s in enumerate(seqs):
+        if strand[i] == 0xFF:                       # an N inside the minimal window, or a tie: left to a tier with room for 4 bits
+            continue
+        done += 1
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i][0], (i, len(s))
+        assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, len(s))
+    assert done >= len(seqs) * 3 // 4, (done, len(seqs))
+    assert {int(strand[i]) for i in range(len(seqs))} >= {0, 1}
+
+
+def test_n_inside_the_minimal_window_prefix_rule():
+    """canon_record_mode2n keeps a winner whose window holds an N when its packed prefix up to that N is unique (forward:
+    j + 1 symbols, reverse: j symbols).  Planted near-ties around that rule, on both strands: the same A-run followed by
+    N / G / T / C at the deciding offset, forward and as reverse complements, in a background that cannot compete."""
+    rng = np.random.default_rng(1400)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    seqs = []
+    for case in range(400):
+        L = int(rng.integers(400, 900))
+        bg = bytearray(rng.choice(list(b"CGT"), size=L, p=[0.2, 0.4, 0.4]).astype(np.uint8).tobytes())     # no A: the planted runs own the minimum
+        run = int(rng.integers(3, 13))
+        k = int(rng.integers(2, 5))
+        spots = sorted(rng.choice(np.arange(20, L - 40, 30), size=k, replace=False))
+        for sp in spots:
+            tail = bytes(rng.choice(list(b"NGTCN"), size=1).astype(np.uint8)) + bytes(rng.choice(list(b"ACGT"), size=6).astype(np.uint8))
+            motif = b"A" * run + tail
+            if rng.random() < 0.5:
+                motif = motif.translate(comp)[::-1]                      # the run shows up on the reverse strand
+            bg[sp:sp + len(motif)] = motif
+        seqs.append(bytes(bg))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    # 100 dwords: room for the 2-bit strand + N bitmask of all of them, for the 4-bit strands of none -- what comes out
+    # here came out of canon_record_mode2n; what it refuses is deferred (and checked with a slice that takes everything)
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=100, n_waves=8, alpha=False)
+    assert status == 0
+    kept_with_n_in_window = 0
+    for i, s in enumerate(seqs):
+        if strand[i] == 0xFF:
+            continue
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i][0], (i, s)
+        assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, s)
+        kept_with_n_in_window += b"N" in want[i][0][:16]
+    assert ndef < len(seqs) * 3 // 4 and kept_with_n_in_window >= 20, (ndef, kept_with_n_in_window)
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=400, n_waves=8, alpha=False)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i][0], (i, s)
+        assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, s)
