@@ -140,7 +140,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
             const uint64_t off = k ? o1 : o0;                           // (o2 is loaded but unused when RPW == 1)
             const uint32_t n = (uint32_t)(k ? o2 : o1) - (uint32_t)off;
             const uint32_t rec = ra + k;
-            bool done = false;
+            bool done = false, tried4 = false;
             if (C::ROWS == 2 && q[0].ok && fast2_eligible(n)) {
                 // 1009..2032 bases: two chunks per lane (c0 + 2t, c0 + 2t + 1); the word behind them is lane t+1's first
                 const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;     // <= 128
@@ -170,11 +170,15 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                     const uint64_t X = ((uint64_t)H << 32) | L, Xn = ((uint64_t)wave_shl1(H) << 32) | wave_shl1(L);
                     const uint64_t W = a16 ? (X << (4 * a16)) | (Xn >> (64 - 4 * a16)) : X;
                     done = fast_canonw<4, HASH, false>(a, lut, hc, rec, off, n, (uint32_t)(W >> 32), (uint32_t)W, b4 != 0);
+                    tried4 = true;
                 } else {
                     done = fast_canon<HASH, AUX, GH, true>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
                 }
             }
-            if (!done) defer_record(a, blk_count, block, rec);       // (no alphabet flag: the edge chunks hold neighbours' bytes too)
+            // The entry's flag: the 4-bit register routine has had this record (a tied 8-symbol key, mostly) -- the rescue
+            // pass, which would run the same routine again, hands it on.  (Otherwise no alphabet flag: the edge chunks hold
+            // neighbours' bytes too.  A flagged record that is pure ACGT itself takes the N-mask mode of the tiers: correct.)
+            if (!done) defer_record(a, blk_count, block, rec, ALPHA && tried4);
         }
         // the previous group's hashes: its slots were complete at the barrier that ended the previous iteration
         if constexpr (GH) {
@@ -223,15 +227,16 @@ struct RescueState {        // per-wave constants of the rescue pass (kept acros
 // before it is being processed -- taken one at a time, a record is three dependent round trips (list entry -> offsets ->
 // bytes) with nothing to hide them behind (measured: 5.4 us per record and wave, 6.6 ms for 10M records).
 constexpr uint32_t RESCUE_CHUNK = 8;
-struct RescueMeta { uint32_t rec, len; uint64_t off; };      // lane L < count: entry L of the chunk
+struct RescueMeta { uint32_t rec, len; uint64_t off; };      // lane L < count: entry L of the chunk (rec: the raw entry, flag included)
 CK_DEV RescueMeta rescue_meta(const CanonArgs& a, const uint32_t* seg, uint64_t first, uint32_t c0, uint32_t count, bool all_records)
 {
     const uint32_t t = lane_id();
     RescueMeta m{ 0, 0, 0 };
     if (t < RESCUE_CHUNK && c0 + t < count) {
-        m.rec = all_records ? (uint32_t)first + c0 + t : seg[c0 + t] & ENTRY_REC;
-        m.off = a.offsets[m.rec];
-        const uint64_t len = a.offsets[m.rec + 1] - m.off;
+        m.rec = all_records ? (uint32_t)first + c0 + t : seg[c0 + t];
+        const uint32_t r = m.rec & ENTRY_REC;
+        m.off = a.offsets[r];
+        const uint64_t len = a.offsets[r + 1] - m.off;
         m.len = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
     }
     return m;
@@ -241,7 +246,7 @@ CK_DEV u32x4 rescue_fetch(const CanonArgs& a, const RescueMeta& m, uint32_t l)
 {
     const uint32_t n = readlane(m.len, l), t = lane_id();
     const uint64_t off = ((uint64_t)readlane((uint32_t)(m.off >> 32), l) << 32) | readlane((uint32_t)m.off, l);
-    if (!fast_eligible(n)) return u32x4{ 0, 0, 0, 0 };
+    if (!fast_eligible(n) || (readlane(m.rec, l) & ENTRY_NOT_ACGT)) return u32x4{ 0, 0, 0, 0 };
     return load16(a.bytes + off + (t >= (n >> 4) ? n - 16 : 16 * t));
 }
 // entry l of a chunk, its 16 bytes per lane in v
@@ -250,10 +255,10 @@ CK_DEV void rescue_one(const CanonArgs& a, const uint32_t* lut, RescueState<HASH
                const RescueMeta& cur, uint32_t l, u32x4 v)
 {
     const uint32_t t = lane_id();
-    const uint32_t rec = readlane(cur.rec, l), n = readlane(cur.len, l);
+    const uint32_t entry = readlane(cur.rec, l), rec = entry & ENTRY_REC, n = readlane(cur.len, l);
     const uint64_t off = ((uint64_t)readlane((uint32_t)(cur.off >> 32), l) << 32) | readlane((uint32_t)cur.off, l);
-    bool done = false, not_acgt = false;
-    if (fast_eligible(n)) {
+    bool done = false, not_acgt = (entry & ENTRY_NOT_ACGT) != 0;       // flagged: the streaming kernel's 4-bit routine has had it
+    if (!not_acgt && fast_eligible(n)) {
         const uint32_t nwf = n >> 4;
         const uint32_t tail_syms = t >= nwf ? (16 - (n & 15)) & 15 : 0;       // the tail lane's symbols move up by this much
         uint32_t miss;
