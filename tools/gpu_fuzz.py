@@ -5,7 +5,8 @@ index builds on a subsample).  Mixtures aimed at the streaming kernel's rare pat
 usage: python tools/gpu_fuzz.py [seed] [records] [profile]   (profile "long": most records 1009..2032 bases -- the
 two-words-per-lane build of the streaming kernel; "nrich": half of the records carry N / '-' -- the batch's mode gets
 MODE_ALPHA: 4-bit register routine in the streaming kernel and the rescue pass; "longn": records of 1..9 kb with a few
-N -- the 2-bit-with-N-mask mode of the LDS tiers and its fallbacks)"""
+N -- the 2-bit-with-N-mask mode of the LDS tiers and its fallbacks; "prefixn": records of 0.4..6 kb without A except for
+planted A-runs followed by N / G / T / C, on both strands -- an N inside the minimal window and near-ties around it)"""
 import os
 import sys
 import time
@@ -33,7 +34,19 @@ def rand(n):
 
 seqs = []
 t0 = time.time()
-for i in range(count):
+if profile == "prefixn":
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    for i in range(count):
+        L = int(rng.integers(400, 6000))
+        bg = bytearray(rng.choice(list(b"CGT"), size=L, p=[0.2, 0.4, 0.4]).astype(np.uint8).tobytes())
+        run = int(rng.integers(3, 14))
+        for sp in sorted(rng.choice(np.arange(20, L - 40, 30), size=int(rng.integers(1, 5)), replace=False)):
+            motif = b"A" * run + bytes(rng.choice(list(b"NGTCN"), size=1).astype(np.uint8)) + bytes(rng.choice(list(b"ACGTN"), size=8, p=[.24, .24, .24, .24, .04]).astype(np.uint8))
+            if rng.random() < 0.5:
+                motif = motif.translate(comp)[::-1]
+            bg[sp:sp + len(motif)] = motif
+        seqs.append(bytes(bg))
+for i in range(0 if profile == "prefixn" else count):
     k = rng.integers(0, 100)
     if profile == "longn":
         L = int(rng.integers(1009, 9000)) if k < 90 else int(rng.integers(48, 1009))
