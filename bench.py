@@ -207,7 +207,7 @@ def main():
         else:
             metric = "canonicalize sequences/sec (%d records, 200b-20kb log-uniform lengths)" % N
             wl = "canonicalize, %d records, lengths log-uniform on [200, 20000], %d bases per GPU%s (BASELINE configs[3])" % (N, total, nvar)
-            kernel = ("canon_mixed_kernel<false> (whole step; per-kernel split in profiles/)" if not nvar else
+            kernel = ("canon_mixed_kernel (whole step; per-kernel split in profiles/)" if not nvar else
                       "canon_rescue_kernel + canon_kernel tiers (whole step; per-kernel split in profiles/)")
             par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
         traffic, traffic_source = pmc_traffic("%s %d x %d" % (args.workload, N, L) + (" n%g" % args.n_frac if nvar else ""))

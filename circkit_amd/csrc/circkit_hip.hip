@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
-    if (!AUX && !ALPHA && (mode & 3) == 3) return;                       // ... or canon_mixed_kernel
+    if (!AUX && !ALPHA && !HASH && (mode & 3) == 3) return;              // ... or canon_mixed_kernel
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
     const bool all_records = (mode & 3) == 3;                           // the streaming kernel stood this batch out
     if (!all_records) {
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 // memory (what the rescue pass did for such a batch), every other record the general LDS routine (what tier A did with the
 // rescue pass's list), so the latency-bound short records and the bandwidth-bound long ones share the CUs instead of
 // following each other in two launches with a list in between.  Segment s = records [s * in_seg_cap, (s + 1) * in_seg_cap);
-// what the slice cannot hold goes to segment s of the list tier A consumes.
-template <bool HASH>
+// what the slice cannot hold goes to segment s of the list tier A consumes.  Batches that also want the XXH3 keep the
+// two-launch path: with the fused hash next to the LDS routine this kernel needed ~115 VGPRs (spills at any useful occupancy).
 __global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out,
                                                                       uint32_t* tiers_busy)
 {
@@ -301,8 +301,7 @@ __global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::Canon
     uint32_t* lutn = lut + ck::FAST_LUT_DW;
     ck::fast_lut_init(lut, threadIdx.x, 256);
     ck::fast_lutn_init(lutn, threadIdx.x, 256);
-    ck::RescueState<HASH, false> st;
-    if (HASH) st.hc = ck::fast_hash_const();
+    ck::RescueState<false, false> st;
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     uint32_t* slice = lds + wib * a.slice_dw;
     uint32_t passed_on = 0, walked = 0;
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::Canon
             const uint32_t rec = (uint32_t)first + i;
             const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
             bool not_acgt = false;
-            if (ck::rescue_direct<HASH, false>(a, lut, st, rec, off, len, not_acgt)) continue;
+            if (ck::rescue_direct<false, false>(a, lut, st, rec, off, len, not_acgt)) continue;
             if (!ck::canon_record(a, rec, slice, lut, lutn, not_acgt)) ck::defer_record(a, blk_count, sgm, rec, not_acgt);
             ck::wave_sync();
         }
@@ -851,7 +850,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         uint32_t* mode_out = c->d_mode;               // straight into pinned host memory: no copy-back, no event
 #endif
         // both alphabets' builds unless the host has decided; the one the mode does not name returns at once
-        const bool mixed_has_it = host_mode && !aux && (host_mode & 3) == 3 && !(host_mode & MODE_ALPHA);
+        const bool mixed_has_it = host_mode && !aux && !d_hash && (host_mode & 3) == 3 && !(host_mode & MODE_ALPHA);
         const bool lean = (!host_mode || !(host_mode & MODE_ALPHA)) && !mixed_has_it, alpha = !host_mode || (host_mode & MODE_ALPHA);
         if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         else if (d_hash) {
@@ -862,7 +861,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         }
     }
-    if (!aux && (!host_mode || ((host_mode & 3) == 3 && !(host_mode & MODE_ALPHA)))) {
+    if (!aux && !d_hash && (!host_mode || ((host_mode & 3) == 3 && !(host_mode & MODE_ALPHA)))) {
         // mode 3, pure ACGT: canon_mixed_kernel takes every record (the rescue pass above stood out); same lists, same
         // segments.  One workgroup per segment when the previous batch was such a batch, else a small walking grid.
         const bool was_mixed = host_mode ? true : ((*c->h_mode & 3) == 3 && !(*c->h_mode & MODE_ALPHA));
@@ -874,8 +873,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
 #else
         uint32_t* mode_out = c->d_mode;
 #endif
-        if (d_hash) hipLaunchKernelGGL(canon_mixed_kernel<true>, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
-        else hipLaunchKernelGGL(canon_mixed_kernel<false>, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+        hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
     }
     const bool tiers_idle = c->h_mode[1] == 1;       // the previous batch's tiers found (next to) nothing: small grids for this one
     // (What the idle tiers cost live, measured by not launching them: 82 us of the 3.70 ms headline step, 116 us of uniq's
