@@ -556,6 +556,39 @@ def test_uniq_insert_pairs_device(ctx, O):
     ctx.use_own_stream()
 
 
+def test_uniq_resolve_device_answers_and_keeps_its_table_private(ctx, O):
+    """circkit_uniq_resolve_device (one shard, one call): first-seen indices and keep flags against the oracle, with a
+    base index, the empty-marker hash among the keys and every key several times; its table holds shard-local values in
+    a layout of its own, so insert / lookup are refused until the next reset."""
+    import torch
+    import circkit_amd
+    rng = np.random.default_rng(13)
+    n, base = 300_000, 5_000_000_000
+    h = (rng.integers(0, 60_000, size=n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+    h[rng.integers(0, n, 40)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_h = torch.from_numpy(h.astype(np.int64)).to(dev)
+    fs = torch.empty(n, dtype=torch.int64, device=dev)
+    keep = torch.empty(n, dtype=torch.bool, device=dev)
+    for _ in range(2):                                              # twice: the second call starts from a used table
+        ctx.uniq_resolve_device(d_h, n, base, fs, keep)
+    ctx.uniq_status()
+    exp = O.uniq_first_seen(h)
+    assert np.array_equal(fs.cpu().numpy().astype(np.uint64), exp + np.uint64(base))
+    assert np.array_equal(keep.cpu().numpy(), exp == np.arange(n, dtype=np.uint64))
+    with pytest.raises(circkit_amd.CirckitError):
+        ctx.uniq_lookup_device(d_h, n, fs)
+    with pytest.raises(circkit_amd.CirckitError):
+        ctx.uniq_insert_device(d_h, n, 0)
+    ctx.uniq_reset(n)
+    ctx.uniq_insert_device(d_h, n, base)
+    ctx.uniq_lookup_device(d_h, n, fs)
+    torch.cuda.synchronize()
+    assert np.array_equal(fs.cpu().numpy().astype(np.uint64), exp + np.uint64(base))
+    ctx.use_own_stream()
+
+
 def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
     """The ROWS == 2 build of the streaming kernel (records up to 2032 bases, two packed words per lane): chosen from the
     batch's lengths -- by the host for host buffers, on the device for device buffers (both builds are launched, the
