@@ -56,6 +56,7 @@ def main():
                          "kernel instead of running alone on the chip (measured: headline 3.71 -> 3.57 ms per step, mixed 2.36 -> 2.23); "
                          "the default 1 = strictly one batch after the other, so that the per-step time IS the kernel chain's time "
                          "and agrees with a rocprofv3 kernel trace of the same command")
+    ap.add_argument("--max-len", type=int, default=20000, help="mixed: upper end of the log-uniform lengths (BASELINE configs[3]: 20000)")
     ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
                     help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
                          "strand duplicates, hash + first-seen); mixed = configs[3] (1M records, L ~ 1/L on [200, 20000])")
@@ -95,7 +96,7 @@ def main():
     if args.workload == "mixed":
         # config 4: lengths with P(L) ~ 1/L on [200, 20000] (log-uniform), seed 45
         N = args.records if args.records is not None else 1_000_000
-        offs = W.log_uniform_offsets(N, 45 + rank)
+        offs = W.log_uniform_offsets(N, 45 + rank, 200, args.max_len)
         total = int(offs[-1])
         d_off = offs.to(dev)
         d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
@@ -205,8 +206,9 @@ def main():
             par = ("records sharded over %d GPU(s); first-seen resolved by one hash-range all-to-all over RCCL (exchange=%s)"
                    % (world, args.exchange)) if use_dist else "1 GPU: the ctx hash table, no collective"
         else:
-            metric = "canonicalize sequences/sec (%d records, 200b-20kb log-uniform lengths)" % N
-            wl = "canonicalize, %d records, lengths log-uniform on [200, 20000], %d bases per GPU%s (BASELINE configs[3])" % (N, total, nvar)
+            metric = "canonicalize sequences/sec (%d records, 200b-%dkb log-uniform lengths)" % (N, args.max_len // 1000)
+            wl = "canonicalize, %d records, lengths log-uniform on [200, %d], %d bases per GPU%s (%s)" % (
+                N, args.max_len, total, nvar, "BASELINE configs[3]" if (N, args.max_len) == (1_000_000, 20000) and not nvar else "variant of BASELINE configs[3]")
             kernel = ("canon_mixed_kernel (whole step; per-kernel split in profiles/)" if not nvar else
                       "canon_rescue_kernel + canon_kernel tiers (whole step; per-kernel split in profiles/)")
             par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
@@ -219,7 +221,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": wl, "records_per_gpu": N, "records_total": world * N,
-                       "record_len": L if args.workload != "mixed" else "200..20000 (mean %d)" % (total // N),
+                       "record_len": L if args.workload != "mixed" else "200..%d (mean %d)" % (args.max_len, total // N),
                        "parallelism": par + ("; steps dealt round-robin to %d HIP streams (one ctx each)" % S if S > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,

@@ -198,8 +198,10 @@ CK_DEV uint32_t pack4_rc(uint32_t d0, uint32_t d1)
 // strand builders.  Ef / Er receive nwv + 2 words each.  Return true when every byte was in the
 // alphabet of the mode.
 // ------------------------------------------------------------------------------------------------
+// team > 1 (2-bit only): wave `member` of `team` builds every team-th trip of rows; the caller joins the waves'
+// verdicts and adds the periodic extension (build_extension2) behind a workgroup barrier.
 template <int BITS>
-CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Er)
+CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Er, uint32_t member = 0, uint32_t team = 1)
 {
     constexpr uint32_t S = 32 / BITS;           // bytes consumed per packed word
     constexpr bool RC_FROM_FWD = BITS == 2;     // 2-bit: the reverse strand is a VIEW of Ef (view_word), never stored
@@ -210,7 +212,7 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
     // first is consumed: a long record is otherwise one exposed HBM round trip per row (measured: tier B of
     // BASELINE config 4 spent 61 % of its wave cycles in s_waitcnt with the VALU 20 % busy).
     constexpr int U = CK_BUILD_ROWS;
-    for (uint32_t w0 = lane; w0 < nwv; w0 += 64 * U) {
+    for (uint32_t w0 = member * 64 * U + lane; w0 < nwv; w0 += team * 64 * U) {
         u32x4 vf[U], vc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -245,6 +247,7 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
         }
     }
     const bool ok = ballot(bad != 0) == 0;
+    if (team > 1) return ok;
     wave_sync();
     // periodic extension: E[nwf] gets the head symbols behind the r tail symbols; E[nwv], E[nwv+1] follow.
     if (lane < 3) {
@@ -737,6 +740,105 @@ CK_DEV int canon_record_mode2n(const CanonArgs& a, uint64_t rec, const uint8_t* 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Team mode: the waves of a workgroup canonicalize ONE pure-ACGT record together, its strand in the workgroup's whole LDS
+// (all the per-wave slices side by side).  For records too long for one wave's slice that would otherwise go down to the
+// one-wave tiers, where 7 to 157 KiB of LDS per wave leave 18 to 1 waves per CU: here the CU keeps its 28 waves, four
+// to a record.  Rows of 64 words are dealt to the waves in turn (build, scans, output); the waves meet in three LDS words
+// (minimal key by atomic min, number of positions that own it, the smallest of them) between workgroup barriers.  Same
+// answers as canon_record_mode<2> on its unique-minimum path; a tie, equal strands or a byte outside ACGT leave the
+// record untouched for the tiers behind.  Every wave of the workgroup runs through the same barriers: all decisions are
+// taken on values read back from LDS.
+// ------------------------------------------------------------------------------------------------
+CK_DEV void build_extension2(uint32_t* Ef, uint32_t n)      // lanes 0..2 of one wave, the strand complete and visible
+{
+    const uint32_t lane = lane_id(), nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
+    if (lane == 0) {
+        if (r) Ef[nwf] = Ef[nwf] | (Ef[0] >> (r * 2));
+    } else if (lane < 3) {
+        const uint32_t e = lane - 1;
+        Ef[nwv + e] = r ? funnel(Ef[e], Ef[e + 1], (16 - r) * 2) : Ef[e];
+    }
+}
+// one strand: minimal key M, how many valid positions own it (2 or more: not unique), the smallest of them
+template <bool RCV>
+CK_DEV void team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, uint32_t team, uint32_t* comm, uint32_t& M, uint32_t& owners, uint32_t& pos)
+{
+    const uint32_t lane = lane_id(), nwv = (n + 15) / 16;
+    if (member == 0 && lane == 0) { comm[0] = ~0u; comm[1] = 0; comm[2] = ~0u; }
+    block_barrier();
+    uint32_t best = ~0u, bestw = 0, ties = 0;
+    for (uint32_t w = member * 64 + lane; w < nwv; w += team * 64) {
+        const uint32_t m = word_min_key<2>(view_word<2, RCV>(E, w * 16, n), view_word<2, RCV>(E, (w + 1) * 16, n));
+        if (m < best || ties == 0) { best = m; bestw = w; ties = 1; }
+        else if (m == best) ++ties;
+    }
+    const uint32_t Mw = wave_min_u32(best);
+    if (lane == 0) lds_atomic_min(comm, Mw);
+    block_barrier();
+    M = comm[0];
+    uint32_t cnt = 0, p = ~0u;
+    if (ties != 0 && best == M) {
+        if (ties > 1) {
+            cnt = 2;                                            // several of this lane's words hold M
+        } else {
+            uint32_t mask = word_eq_mask<2>(view_word<2, RCV>(E, bestw * 16, n), view_word<2, RCV>(E, (bestw + 1) * 16, n), M);
+            const uint32_t valid = n - bestw * 16;
+            if (valid < 16) mask &= (1u << valid) - 1u;         // the last word's positions behind the record end repeat word 0's
+            cnt = (uint32_t)popc32(mask);
+            if (mask) p = bestw * 16 + (uint32_t)ffs32(mask);
+        }
+    }
+    const uint32_t cw = (uint32_t)wave_sum_u64(cnt), pw = wave_min_u32(p);
+    if (lane == 0 && cw) { lds_atomic_add(comm + 1, cw); lds_atomic_min(comm + 2, pw); }
+    block_barrier();
+    owners = comm[1]; pos = comm[2];
+    block_barrier();                                            // everybody has the answers before the words are reset
+}
+// lds: the workgroup's slices (team * slice_dw dwords); comm: three LDS words
+CK_DEV bool canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, uint32_t* comm, uint32_t member, uint32_t team)
+{
+    const uint64_t off = a.offsets[rec];
+    const uint32_t n = (uint32_t)(a.offsets[rec + 1] - off), nwv = (n + 15) / 16, lane = lane_id();
+    const uint8_t* src = a.bytes + off;
+    uint32_t* E = lds;
+    if (member == 0 && lane == 0) comm[0] = 0;
+    block_barrier();
+    if (!build_packed<2>(src, n, E, E, member, team) && lane == 0) lds_atomic_or(comm, 1u);
+    block_barrier();
+    const bool not_acgt = comm[0] != 0;
+    if (member == 0) build_extension2(E, n);
+    block_barrier();                                            // (also: comm[0] has been read by everybody)
+    if (not_acgt) return false;
+    const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
+    uint32_t MF, oF, pF, MC = ~0u, oC = 1, pC = 0;
+    team_scan_locate<false>(E, n, member, team, comm, MF, oF, pF);
+    if (!fwd_only) team_scan_locate<true>(E, n, member, team, comm, MC, oC, pC);
+    // lib/src/canonicalize.rs:58-62: forward only if strictly smaller; equal minimal keys need the full comparison, a
+    // minimal key with several owners the duel: both are the one-wave tiers' business
+    if (!fwd_only && MF == MC) return false;
+    const bool fwd = fwd_only || MF < MC;
+    if ((fwd ? oF : oC) != 1) return false;
+    if (!fwd && a.out_index && oF != 1) return false;          // the reference-visible index counts from the forward minimum
+    const uint32_t idx = fwd ? pF : pC;
+    if (a.out_bytes) {
+        uint8_t* out = a.out_bytes + off;
+        for (uint32_t w = member * 64 + lane; w < nwv; w += team * 64) {
+            const u32x4 o = fwd ? decode_word<2, false>(E, idx + w * 16, n, lut) : decode_word<2, true>(E, idx + w * 16, n, lut);
+            const uint32_t left = n - w * 16;
+            store_bytes(out + w * 16, o, left < 16 ? left : 16);
+        }
+    }
+    if (member == 0 && lane == 0) {
+        if (a.out_index) a.out_index[rec] = fwd ? pF : (pC + pF) % n;               // unique minima: period n
+        if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+    }
+    block_barrier();                                            // the strand is read to the end before the next record's build
+    return true;
+}
+// a record the team takes: too long for one wave's slice, short enough for all of them together
+CK_DEV bool team_takes(uint32_t n, uint32_t slice_dw, uint32_t team) { return need_dw_strand2(n) > slice_dw && need_dw_strand2(n) <= team * slice_dw; }
+
 // List entries: bits 0..30 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
 // that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte).
 constexpr uint32_t ENTRY_NOT_ACGT = 0x80000000u, ENTRY_REC = 0x7FFFFFFFu;
@@ -821,6 +923,32 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
             wave_sync();
         }
     }
+}
+
+// Team pass of a workgroup over the deferral segment it has just written (every wave, behind a workgroup barrier):
+// entries the team can take (team_takes, pure ACGT as far as anybody knows) are canonicalized by all waves together and
+// leave the segment, the others move up.  blk_count[0] = entries, blk_count[1..3] = the team's three words.
+CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, uint32_t* blk_count, uint32_t block, uint32_t wib, uint32_t wpb)
+{
+    const uint32_t cnt = *blk_count;
+    if (cnt == 0 || !a.defer_list) return;
+    uint32_t* seg = a.defer_list + (uint64_t)block * a.out_seg_cap;
+    uint32_t kept = 0;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        const uint32_t entry = seg[k], rec = entry & ENTRY_REC;      // written by this workgroup before the barrier
+        bool done = false;
+        if (!(entry & ENTRY_NOT_ACGT)) {
+            const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
+            if (len < (1ull << 31) && team_takes((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb);
+        }
+        if (!done) {
+            if (wib == 0 && lane_id() == 0 && kept != k) seg[kept] = entry;
+            ++kept;
+        }
+    }
+    block_barrier();
+    if (wib == 0 && lane_id() == 0) *blk_count = kept;
+    block_barrier();
 }
 
 }  // namespace ck

@@ -211,6 +211,8 @@ CK_DEV uint32_t load4(const uint8_t* p)
 CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 CK_DEV uint32_t lds_atomic_inc(uint32_t* p) { return atomicAdd(p, 1u); }     // p in LDS: ds_add_rtn_u32
 CK_DEV void lds_atomic_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+CK_DEV void lds_atomic_min(uint32_t* p, uint32_t v) { atomicMin(p, v); }
+CK_DEV void lds_atomic_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 
 // Two consecutive u64 (a CSR offset pair) through the scalar cache: s_load_dwordx4, tracked by lgkmcnt, so
 // it never forces a vmcnt(0) that would drain the prefetched record bytes.  The wait is INSIDE the same asm

@@ -140,10 +140,13 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 
 namespace {
 struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false; };
-void wave_body(void* p)
+void wave_body(void* p)          // one fiber of a 4-wave workgroup of the LDS tier (canon_kernel<4>)
 {
     Launch* L = (Launch*)p;
-    ck::canon_wave_loop(L->a, L->lds, L->lut, L->blk_count, L->block, L->nblocks, L->wib, 4, L->lutn);
+    const uint32_t wib = ck::emu::cur_wave();
+    ck::canon_wave_loop(L->a, L->lds + wib * L->a.slice_dw, L->lut, L->blk_count, L->block, L->nblocks, wib, 4, L->lutn);
+    ck::block_barrier();
+    ck::team_pass(L->a, L->lds, L->lut, L->blk_count, L->block, wib, 4);
 }
 void rescue_body(void* p)
 {
@@ -252,10 +255,10 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a.list = list_r.data(); L.a.list_count = cnt_r.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1;
     L.a.defer_list = list_a.data(); L.a.defer_count = cnt_a.data(); L.a.out_seg_cap = cap; L.a.slice_dw = slice_dw;
     for (uint32_t b = 0; b < G; ++b) {
-        uint32_t blk = 0;
-        L.block = b; L.blk_count = &blk;
-        for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(wave_body, &L); }
-        cnt_a[b] = blk; total_a += blk;
+        uint32_t blk[4] = { 0, 0, 0, 0 };           // deferral counter + the team's three words
+        L.block = b; L.blk_count = blk;
+        ck::emu::run_block(wave_body, &L, 4);
+        cnt_a[b] = blk[0]; total_a += blk[0];
     }
     if (n_deferred) *n_deferred = total_a;
     if (out_hash) {     // the xxh3 pass for whatever the streaming kernel did not hash

@@ -125,6 +125,8 @@ CK_DEV uint32_t load4(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v
 CK_DEV uint32_t atomic_add_u32(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 CK_DEV uint32_t lds_atomic_inc(uint32_t* p) { return (*p)++; }
 CK_DEV void lds_atomic_or(uint32_t* p, uint32_t v) { *p |= v; }
+CK_DEV void lds_atomic_min(uint32_t* p, uint32_t v) { if (v < *p) *p = v; }
+CK_DEV void lds_atomic_add(uint32_t* p, uint32_t v) { *p += v; }
 struct ck_u32x4v { uint32_t x, y, z, w; };
 CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), gsrc, 16); }
 CK_DEV void glds16_async_s(uint32_t* lds_dst, const uint8_t* sbase, uint32_t voff) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), sbase + voff, 16); }

@@ -51,9 +51,11 @@ def test_long_records_multi_row():
 
 
 def test_deferral_to_bigger_tier():
-    seqs = seqsets.random_mixed(30, 20, 100, 3000)
-    n = check(seqs, slice_dw=120)                  # the 2-bit strand of a record up to 1888 bases fits (no bitmask needed)
-    assert 0 < n < len(seqs)
+    # a 120-dword slice: one wave takes the 2-bit strand of a record up to 1888 bases (no bitmask needed), the four waves
+    # of the workgroup together (team mode) up to 7648; beyond that the record is deferred
+    seqs = seqsets.random_mixed(30, 12, 100, 3000) + seqsets.random_mixed(35, 6, 8000, 12000) + seqsets.random_mixed(36, 4, 3000, 7600)
+    n = check(seqs, slice_dw=120)
+    assert n == 6
 
 
 def test_tied_minimal_key_without_room_for_the_bitmask_moves_on():
@@ -369,3 +371,41 @@ def test_n_inside_the_minimal_window_prefix_rule():
         a, b = int(offs[i]), int(offs[i + 1])
         assert out[a:b].tobytes() == want[i][0], (i, s)
         assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, s)
+
+
+def test_team_mode_four_waves_one_record():
+    """Records too long for one wave's slice (here 120 dwords: 1888 bases) and short enough for the workgroup's four
+    slices together (7648) are canonicalized by the four waves as a team: rows dealt in turn, minimal key / owners /
+    position joined through three LDS words.  Lengths around the row (1024 bases) and word boundaries, both strands,
+    rotation index and strand; a tandem repeat (tied minimal key), a reverse-complement palindrome (equal strands) and
+    a record with an N are left untouched for the tiers behind."""
+    rng = np.random.default_rng(1500)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    seqs = []
+    for L in [1889, 1890, 1904, 1905, 2047, 2048, 2049, 3071, 3072, 3073, 4095, 4096, 4097, 4112, 5000, 6143, 6144, 6145, 7000, 7647, 7648]:
+        seqs.append(seqsets.random_mixed(1501 + L, 1, L, L)[0])
+    unit = bytes(rng.choice(list(b"ACGT"), size=977).astype(np.uint8))
+    half = seqsets.random_mixed(1502, 1, 1500, 1500)[0]
+    withn = bytearray(seqsets.random_mixed(1503, 1, 4000, 4000)[0]); withn[2500] = ord("N")
+    odd = [(unit * 5)[:4000], half + half.translate(comp)[::-1], bytes(withn)]
+    seqs += odd
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False)
+    assert status == 0 and ndef == len(odd)
+    strands = set()
+    for i, s in enumerate(seqs[:-len(odd)]):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert strand[i] != 0xFF, (i, len(s))
+        assert out[a:b].tobytes() == want[i][0], (i, len(s))
+        assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, len(s))
+        strands.add(int(strand[i]))
+    assert strands == {0, 1}
+    for i in range(len(seqs) - len(odd), len(seqs)):
+        assert strand[i] == 0xFF                       # untouched
+    # and with room for everything in one wave's slice the same records take the one-wave path: same answers
+    out2, idx2, strand2, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=4096, n_waves=8, alpha=False)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out2[a:b].tobytes() == want[i][0] and (int(strand2[i]), int(idx2[i])) == (want[i][1], want[i][2]), (i, len(s))

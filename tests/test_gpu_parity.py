@@ -156,6 +156,37 @@ def test_records_beyond_the_lds_tiers(ctx, O):
     _check(ctx, O, seqs)
 
 
+def test_team_mode_records_of_20_to_80_kb(ctx, O):
+    """Records too long for one wave's 5 KiB slice of tier A (2-bit: 20.4 kb) and short enough for the four slices of a
+    workgroup together (81 kb) are canonicalized by the workgroup's four waves as a team -- in canon_kernel<4> (all
+    outputs, host API) and in canon_mixed_kernel (bytes only, mode decided on the device).  Lengths around the row and
+    slice limits; a tandem repeat, a reverse-complement palindrome and records with N take the tiers behind."""
+    import torch
+    from tests import seqsets
+    rng = np.random.default_rng(21)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    lens = [20417, 20448, 20449, 24575, 24576, 24577, 32768, 40000, 49151, 49152, 65536, 81855, 81856, 81857, 81888, 81889, 90000]
+    seqs = [acgt[rng.integers(0, 4, L)].tobytes() for L in lens]
+    half = acgt[rng.integers(0, 4, 15000)].tobytes()
+    withn = bytearray(acgt[rng.integers(0, 4, 50000)].tobytes()); withn[33333] = ord("N")
+    seqs += [(acgt[rng.integers(0, 4, 977)].tobytes() * 40)[:30000], half + half.translate(comp)[::-1], bytes(withn)]
+    seqs = seqsets.random_mixed(91, 40, 200, 20000) + seqs + seqsets.random_mixed(92, 300, 48, 1008)
+    _check(ctx, O, seqs)
+    data, offs = seqsets.pack(seqs)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    exp, _ = O.canonicalize_batch(data, offs, True, False, threads=8)
+    for _ in range(2):                                       # the second batch runs with the first one's launch hints
+        d_out = torch.zeros_like(d_bytes)
+        ctx.canonicalize_batch_device(d_bytes, d_off, len(seqs), out_bytes=d_out)
+        assert ctx.batch_status() == 0
+        assert np.array_equal(d_out.cpu().numpy(), exp)
+    ctx.use_own_stream()
+
+
 def test_device_api_finishes_long_records_on_the_device(ctx, O):
     """Device API: the batch call enqueues everything, records beyond the LDS tiers included (global-scratch stages);
     any synchronisation with the stream is enough."""
