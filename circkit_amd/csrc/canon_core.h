@@ -606,13 +606,24 @@ CK_DEV uint32_t nmask16_at(const uint32_t* Nb, uint32_t p, uint32_t n)
 }
 // forward words (+ periodic extension) and the N bitmask (32 symbols per dword, first symbol in the top bit, extended
 // periodically by 32 symbols or more); returns false when a byte is outside ACGTN
-CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Nb)
+// the N bitmask's periodic extension (one lane; strand-sized masks complete and visible): symbols n .. n + 32 (or more)
+// repeat symbols 0 ..; the bits past n in dword n / 32 are zero so far
+CK_DEV void build_extension_nb(uint32_t* Nb, uint32_t n)
+{
+    const uint32_t q = n & 31, nd = n >> 5, a0 = Nb[0];
+    const uint32_t x = q ? (Nb[nd] | (a0 >> q)) : a0;
+    const uint32_t a1 = nd == 1 ? x : Nb[1];
+    Nb[nd] = x;
+    Nb[nd + 1] = q ? ((a0 << (32 - q)) | (a1 >> q)) : a1;
+}
+// team > 1: wave `member` builds every team-th trip of rows and leaves the extensions to the caller (team mode)
+CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Nb, uint32_t member = 0, uint32_t team = 1)
 {
     const uint32_t lane = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
     uint32_t bad = 0;
     constexpr int U = CK_BUILD_ROWS;
-    for (uint32_t w0 = 0; w0 < nwv; w0 += 64 * U) {             // (wave-uniform trip count: the mask halves meet by DPP)
+    for (uint32_t w0 = member * 64 * U; w0 < nwv; w0 += team * 64 * U) {             // (wave-uniform trip count: the mask halves meet by DPP)
         u32x4 vf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -635,6 +646,7 @@ CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_
         }
     }
     const bool ok = ballot(bad != 0) == 0;
+    if (team > 1) return ok;
     wave_sync();
     if (lane < 3) {
         if (lane == 0) {
@@ -644,12 +656,7 @@ CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_
             Ef[nwv + e] = r ? funnel(Ef[e], Ef[e + 1], (16 - r) * 2) : Ef[e];
         }
     } else if (lane == 3) {
-        // mask: symbols n .. n + 32 (or more) repeat symbols 0 ..; the bits past n in dword n / 32 are zero so far
-        const uint32_t q = n & 31, nd = n >> 5, a0 = Nb[0];
-        const uint32_t x = q ? (Nb[nd] | (a0 >> q)) : a0;
-        const uint32_t a1 = nd == 1 ? x : Nb[1];
-        Nb[nd] = x;
-        Nb[nd + 1] = q ? ((a0 << (32 - q)) | (a1 >> q)) : a1;
+        build_extension_nb(Nb, n);
     }
     wave_sync();
     return ok;
@@ -657,12 +664,13 @@ CK_DEV bool build_packed2n(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_
 CK_DEV uint32_t need_dw_2n(uint32_t n) { return (n + 15) / 16 + 2 + (n >> 5) + 2; }
 
 // how many of the strand's n positions start a key that agrees with K in its first 32 - sh bits (simple loop: rare path)
+// (member / team: this wave's share of the rows in team mode)
 template <class WordAt>
-CK_DEV uint32_t count_prefix2(WordAt word_at, uint32_t n, uint32_t K, uint32_t sh)
+CK_DEV uint32_t count_prefix2(WordAt word_at, uint32_t n, uint32_t K, uint32_t sh, uint32_t member = 0, uint32_t team = 1)
 {
     const uint32_t nwv = (n + 15) / 16;
     uint32_t cnt = 0;
-    for (uint32_t w = lane_id(); w < nwv; w += 64) {
+    for (uint32_t w = member * 64 + lane_id(); w < nwv; w += team * 64) {
         const uint32_t cur = word_at(w * 16), nxt = word_at((w + 1) * 16);
         const uint32_t valid = n - w * 16 < 16 ? n - w * 16 : 16;
         for (uint32_t b = 0; b < valid; ++b) cnt += ((funnel(cur, nxt, 2 * b) ^ K) >> sh) == 0 ? 1u : 0u;
@@ -839,6 +847,76 @@ CK_DEV bool canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, 
 // a record the team takes: too long for one wave's slice, short enough for all of them together
 CK_DEV bool team_takes(uint32_t n, uint32_t slice_dw, uint32_t team) { return need_dw_strand2(n) > slice_dw && need_dw_strand2(n) <= team * slice_dw; }
 
+// The same for a record with a few N (canon_record_mode2n's rules: N packed as G, one mask bit per symbol, scans that never
+// read the mask, the prefix rule for an N inside the winning window).  false: left for the 4-bit mode of the tiers behind.
+CK_DEV bool canon_record_team2n(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, uint32_t* comm,
+                                uint32_t member, uint32_t team)
+{
+    const uint64_t off = a.offsets[rec];
+    const uint32_t n = (uint32_t)(a.offsets[rec + 1] - off), nwv = (n + 15) / 16, lane = lane_id();
+    const uint8_t* src = a.bytes + off;
+    uint32_t* E = lds;
+    uint32_t* Nb = lds + (nwv + 2);
+    if (member == 0 && lane == 0) comm[0] = 0;
+    block_barrier();
+    if (!build_packed2n(src, n, E, Nb, member, team) && lane == 0) lds_atomic_or(comm, 1u);
+    block_barrier();
+    const bool refused = comm[0] != 0;
+    if (member == 0) { build_extension2(E, n); if (lane == 3) build_extension_nb(Nb, n); }
+    block_barrier();
+    if (refused) return false;
+    const auto mirror = [&](uint32_t p) {
+        p = p >= n ? p - n : p;
+        const int32_t s0 = (int32_t)n - 16 - (int32_t)p;
+        return (uint32_t)(s0 + ((s0 >> 31) & (int32_t)n));
+    };
+    const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
+    uint32_t MF, oF, pF, MC = ~0u, oC = 1, pC = 0;
+    team_scan_locate<false>(E, n, member, team, comm, MF, oF, pF);
+    if (!fwd_only) team_scan_locate<true>(E, n, member, team, comm, MC, oC, pC);
+    if (!fwd_only && MF == MC) return false;
+    const bool fwd = fwd_only || MF < MC;
+    if ((fwd ? oF : oC) != 1) return false;
+    const uint32_t pos = fwd ? pF : pC;
+    const uint32_t mw = fwd ? nmask16_at(Nb, pos, n) : bitrev(nmask16_at(Nb, mirror(pos), n)) >> 16;
+    if (mw != 0) {                                              // the prefix rule (see canon_record_mode2n)
+        const uint32_t j = (uint32_t)clz32(mw) - 16, plen = fwd ? j + 1 : j;
+        if (plen == 0) return false;
+        const uint32_t sh = 32 - 2 * plen, K = fwd ? MF : MC;
+        if (member == 0 && lane == 0) comm[1] = 0;
+        block_barrier();
+        uint32_t c = count_prefix2([&](uint32_t p) { return view_word<2, false>(E, p, n); }, n, K, sh, member, team);
+        if (!fwd_only) c += count_prefix2([&](uint32_t p) { return view_word<2, true>(E, p, n); }, n, K, sh, member, team);
+        if (lane == 0 && c) lds_atomic_add(comm + 1, c);
+        block_barrier();
+        const uint32_t sharers = comm[1];
+        block_barrier();
+        if (sharers != 1) return false;
+    }
+    if (!fwd && a.out_index && (oF != 1 || nmask16_at(Nb, pF, n) != 0)) return false;
+    if (a.out_bytes) {
+        uint8_t* out = a.out_bytes + off;
+        const uint32_t fix = fwd ? 0x09u : 0x0Du;                               // 'G' ^ 'N', 'C' ^ 'N'
+        for (uint32_t w = member * 64 + lane; w < nwv; w += team * 64) {
+            const uint32_t p = pos + w * 16;
+            const uint32_t m = fwd ? nmask16_at(Nb, p, n) : bitrev(nmask16_at(Nb, mirror(p), n)) >> 16;
+            u32x4 o = fwd ? decode_word<2, false>(E, p, n, lut) : decode_word<2, true>(E, p, n, lut);
+            if (m) {
+                o.x ^= lutn[m >> 12] * fix; o.y ^= lutn[(m >> 8) & 15] * fix; o.z ^= lutn[(m >> 4) & 15] * fix; o.w ^= lutn[m & 15] * fix;
+            }
+            const uint32_t left = n - w * 16;
+            store_bytes(out + w * 16, o, left < 16 ? left : 16);
+        }
+    }
+    if (member == 0 && lane == 0) {
+        if (a.out_index) a.out_index[rec] = fwd ? pF : (pC + pF) % n;
+        if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+    }
+    block_barrier();
+    return true;
+}
+CK_DEV bool team_takes_2n(uint32_t n, uint32_t slice_dw, uint32_t team) { return n >= 48 && need_dw_2n(n) > slice_dw && need_dw_2n(n) <= team * slice_dw; }
+
 // List entries: bits 0..30 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
 // that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte).
 constexpr uint32_t ENTRY_NOT_ACGT = 0x80000000u, ENTRY_REC = 0x7FFFFFFFu;
@@ -928,7 +1006,7 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
 // Team pass of a workgroup over the deferral segment it has just written (every wave, behind a workgroup barrier):
 // entries the team can take (team_takes, pure ACGT as far as anybody knows) are canonicalized by all waves together and
 // leave the segment, the others move up.  blk_count[0] = entries, blk_count[1..3] = the team's three words.
-CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, uint32_t* blk_count, uint32_t block, uint32_t wib, uint32_t wpb)
+CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, uint32_t* blk_count, uint32_t block, uint32_t wib, uint32_t wpb)
 {
     const uint32_t cnt = *blk_count;
     if (cnt == 0 || !a.defer_list) return;
@@ -937,9 +1015,12 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, ui
     for (uint32_t k = 0; k < cnt; ++k) {
         const uint32_t entry = seg[k], rec = entry & ENTRY_REC;      // written by this workgroup before the barrier
         bool done = false;
-        if (!(entry & ENTRY_NOT_ACGT)) {
-            const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
-            if (len < (1ull << 31) && team_takes((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb);
+        const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
+        if (len < (1ull << 31)) {
+            // an entry without the alphabet flag is pure ACGT as far as anybody knows (if not, the 2-bit team finds out and
+            // the N-mask team has the next look); a flagged one holds an N, a gap or worse
+            if (!(entry & ENTRY_NOT_ACGT) && team_takes((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb);
+            if (!done && lutn && team_takes_2n((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, wpb);
         }
         if (!done) {
             if (wib == 0 && lane_id() == 0 && kept != k) seg[kept] = entry;

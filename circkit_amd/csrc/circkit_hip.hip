@@ -71,7 +71,7 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
         __syncthreads();
         ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, vb, nvb, wib, WPB, lutn);
         __syncthreads();
-        if (WPB > 1) ck::team_pass(a, lds, lut, blk_count, vb, wib, WPB);      // records too long for one wave's slice: all waves together
+        if (WPB > 1) ck::team_pass(a, lds, lut, lutn, blk_count, vb, wib, WPB);      // records too long for one wave's slice: all waves together
         if (threadIdx.x == 0 && a.defer_count) a.defer_count[vb] = *blk_count;
         if (threadIdx.x == 0 && giants && *blk_count) atomicAdd(giants, *blk_count);     // last LDS tier: tell the global-scratch kernel there is work
     }
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::Canon
             ck::wave_sync();
         }
         __syncthreads();
-        ck::team_pass(a, lds, lut, blk_count, sgm, wib, 4);
+        ck::team_pass(a, lds, lut, nullptr, blk_count, sgm, wib, 4);      // (pure-ACGT batches: the odd record with an N waits for tier A's N-mask team)
         if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
     }
     if (threadIdx.x == 0 && passed_on > walked) *tiers_busy = 1;

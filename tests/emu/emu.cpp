@@ -146,7 +146,7 @@ void wave_body(void* p)          // one fiber of a 4-wave workgroup of the LDS t
     const uint32_t wib = ck::emu::cur_wave();
     ck::canon_wave_loop(L->a, L->lds + wib * L->a.slice_dw, L->lut, L->blk_count, L->block, L->nblocks, wib, 4, L->lutn);
     ck::block_barrier();
-    ck::team_pass(L->a, L->lds, L->lut, L->blk_count, L->block, wib, 4);
+    ck::team_pass(L->a, L->lds, L->lut, L->lutn, L->blk_count, L->block, wib, 4);
 }
 void rescue_body(void* p)
 {

@@ -377,8 +377,8 @@ def test_team_mode_four_waves_one_record():
     """Records too long for one wave's slice (here 120 dwords: 1888 bases) and short enough for the workgroup's four
     slices together (7648) are canonicalized by the four waves as a team: rows dealt in turn, minimal key / owners /
     position joined through three LDS words.  Lengths around the row (1024 bases) and word boundaries, both strands,
-    rotation index and strand; a tandem repeat (tied minimal key), a reverse-complement palindrome (equal strands) and
-    a record with an N are left untouched for the tiers behind."""
+    rotation index and strand; a tandem repeat (tied minimal key) and a reverse-complement palindrome (equal strands)
+    are left untouched for the tiers behind."""
     rng = np.random.default_rng(1500)
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     seqs = []
@@ -387,7 +387,8 @@ def test_team_mode_four_waves_one_record():
     unit = bytes(rng.choice(list(b"ACGT"), size=977).astype(np.uint8))
     half = seqsets.random_mixed(1502, 1, 1500, 1500)[0]
     withn = bytearray(seqsets.random_mixed(1503, 1, 4000, 4000)[0]); withn[2500] = ord("N")
-    odd = [(unit * 5)[:4000], half + half.translate(comp)[::-1], bytes(withn)]
+    seqs.append(bytes(withn))                          # one N: the N-mask team (canon_record_team2n) has it
+    odd = [(unit * 5)[:4000], half + half.translate(comp)[::-1]]
     seqs += odd
     data, offs = seqsets.pack(seqs)
     want = [seqsets.expected(O, s) for s in seqs]
@@ -409,3 +410,42 @@ def test_team_mode_four_waves_one_record():
     for i, s in enumerate(seqs):
         a, b = int(offs[i]), int(offs[i + 1])
         assert out2[a:b].tobytes() == want[i][0] and (int(strand2[i]), int(idx2[i])) == (want[i][1], want[i][2]), (i, len(s))
+
+
+def test_team_mode_with_n_bitmask():
+    """The N-mask team: records with a few N that are too long for one wave's slice (120 dwords: strand + bitmask of
+    ~1.2 kb) and fit the workgroup's four slices (~5 kb).  Random N at 0.1-2 %, lengths around the row boundaries, and
+    the planted near-ties of the prefix rule (an N inside the minimal window) on both strands."""
+    rng = np.random.default_rng(1600)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    seqs = []
+    for L in [1300, 1536, 2047, 2048, 2049, 2064, 3000, 3071, 3072, 3073, 4000, 4096, 4097, 5000, 5072]:
+        for frac in (0.001, 0.02):
+            s = bytearray(seqsets.random_mixed(1601 + L, 1, L, L)[0])
+            for p in rng.integers(0, L, size=max(1, int(L * frac))):
+                s[int(p)] = ord("N")
+            seqs.append(bytes(s))
+    for case in range(120):
+        L = int(rng.integers(1400, 5000))
+        bg = bytearray(rng.choice(list(b"CGT"), size=L, p=[0.2, 0.4, 0.4]).astype(np.uint8).tobytes())
+        run = int(rng.integers(3, 13))
+        for sp in sorted(rng.choice(np.arange(20, L - 40, 30), size=int(rng.integers(2, 5)), replace=False)):
+            motif = b"A" * run + bytes(rng.choice(list(b"NGTCN"), size=1).astype(np.uint8)) + bytes(rng.choice(list(b"ACGT"), size=6).astype(np.uint8))
+            if rng.random() < 0.5:
+                motif = motif.translate(comp)[::-1]
+            bg[sp:sp + len(motif)] = motif
+        seqs.append(bytes(bg))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False)
+    assert status == 0
+    done = kept_with_n_in_window = 0
+    for i, s in enumerate(seqs):
+        if strand[i] == 0xFF:
+            continue
+        done += 1
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i][0], (i, len(s))
+        assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, len(s))
+        kept_with_n_in_window += b"N" in want[i][0][:16]
+    assert done >= len(seqs) // 2 and kept_with_n_in_window >= 3, (done, len(seqs), kept_with_n_in_window)
