@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 // table).  A 2-bit record needs its ONE stored strand, n / 16 + 2 dwords (+ n / 32 for the candidate bitmask only if the
 // minimal key ties); with a few N the strand + n / 32 of N bitmask; 4-bit and byte mode two strands + the bitmask.
 //   A: 4 waves x 5 KiB per workgroup (7 workgroups per CU)    2-bit records up to ~20.4 kb: all of BASELINE config 4
-//   A (cont.)                                                 ... with a few N up to ~13.6 kb
+//   A (cont.)                                                 ... with a few N up to ~13.6 kb; the four waves as a TEAM on one
+//                                                             record (canon_core.h team mode): 2-bit up to ~81 kb, few N ~54 kb
 //   B1: 1 wave x 7.4 KiB (18 per CU)                          2-bit up to ~30 kb, with a few N up to ~20.2 kb
 //   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~53 kb, with a few N up to ~35 kb
 //   C: 1 wave x 39 KiB (3 per CU)                             2-bit up to ~160 kb, byte-mode up to ~17 kb
