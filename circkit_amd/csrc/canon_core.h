@@ -804,7 +804,8 @@ CK_DEV void team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, uin
     block_barrier();                                            // everybody has the answers before the words are reset
 }
 // lds: the workgroup's slices (team * slice_dw dwords); comm: three LDS words
-CK_DEV bool canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, uint32_t* comm, uint32_t member, uint32_t team)
+// returns 0: done; 1: a byte outside ACGT; 2: a tie / equal strands (the general routine's business)
+CK_DEV int canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, uint32_t* comm, uint32_t member, uint32_t team)
 {
     const uint64_t off = a.offsets[rec];
     const uint32_t n = (uint32_t)(a.offsets[rec + 1] - off), nwv = (n + 15) / 16, lane = lane_id();
@@ -817,17 +818,17 @@ CK_DEV bool canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, 
     const bool not_acgt = comm[0] != 0;
     if (member == 0) build_extension2(E, n);
     block_barrier();                                            // (also: comm[0] has been read by everybody)
-    if (not_acgt) return false;
+    if (not_acgt) return 1;
     const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
     uint32_t MF, oF, pF, MC = ~0u, oC = 1, pC = 0;
     team_scan_locate<false>(E, n, member, team, comm, MF, oF, pF);
     if (!fwd_only) team_scan_locate<true>(E, n, member, team, comm, MC, oC, pC);
     // lib/src/canonicalize.rs:58-62: forward only if strictly smaller; equal minimal keys need the full comparison, a
     // minimal key with several owners the duel: both are the one-wave tiers' business
-    if (!fwd_only && MF == MC) return false;
+    if (!fwd_only && MF == MC) return 2;
     const bool fwd = fwd_only || MF < MC;
-    if ((fwd ? oF : oC) != 1) return false;
-    if (!fwd && a.out_index && oF != 1) return false;          // the reference-visible index counts from the forward minimum
+    if ((fwd ? oF : oC) != 1) return 2;
+    if (!fwd && a.out_index && oF != 1) return 2;          // the reference-visible index counts from the forward minimum
     const uint32_t idx = fwd ? pF : pC;
     if (a.out_bytes) {
         uint8_t* out = a.out_bytes + off;
@@ -842,7 +843,7 @@ CK_DEV bool canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, 
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
     block_barrier();                                            // the strand is read to the end before the next record's build
-    return true;
+    return 0;
 }
 // a record the team takes: too long for one wave's slice, short enough for all of them together
 CK_DEV bool team_takes(uint32_t n, uint32_t slice_dw, uint32_t team) { return need_dw_strand2(n) > slice_dw && need_dw_strand2(n) <= team * slice_dw; }
@@ -1019,8 +1020,9 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, co
         if (len < (1ull << 31)) {
             // an entry without the alphabet flag is pure ACGT as far as anybody knows (if not, the 2-bit team finds out and
             // the N-mask team has the next look); a flagged one holds an N, a gap or worse
-            if (!(entry & ENTRY_NOT_ACGT) && team_takes((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb);
-            if (!done && lutn && team_takes_2n((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, wpb);
+            int why = (entry & ENTRY_NOT_ACGT) ? 1 : 3;            // 3: not tried
+            if (why == 3 && team_takes((uint32_t)len, a.slice_dw, wpb)) { why = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb); done = why == 0; }
+            if (why == 1 && lutn && team_takes_2n((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, wpb);
         }
         if (!done) {
             if (wib == 0 && lane_id() == 0 && kept != k) seg[kept] = entry;

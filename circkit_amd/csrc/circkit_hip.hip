@@ -77,6 +77,70 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
     }
 }
 
+// The last LDS stage: one 16-wave workgroup with the CU's whole LDS.  A record the team can take -- its 2-bit strand (with a
+// few N: + the bitmask) fits 157 KiB: pure ACGT up to ~640 kb -- is canonicalized by the sixteen waves together
+// (canon_core.h team mode) where the one-wave tier this replaces ran ONE wave per CU; everything else (4-bit and byte
+// modes, ties, reverse-complement palindromes) is wave 0's alone with the same LDS, as before, the others waiting at the
+// barrier.  a.slice_dw = a sixteenth of the LDS dwords.
+constexpr int TEAM_WAVES = 16;
+__global__ __launch_bounds__(TEAM_WAVES * 64) void canon_team_kernel(ck::CanonArgs a, uint32_t nvb, uint32_t* giants)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t total_dw = TEAM_WAVES * a.slice_dw;
+    uint32_t* blk_count = lds + total_dw;
+    uint32_t* lut = blk_count + 4;
+    uint32_t* lutn = lut + ck::FAST_LUT_DW;
+    {
+        // nothing in any of this workgroup's input segments (every ordinary batch): one parallel look, done
+        const uint32_t per = a.segs_per_block, mine = blockIdx.x < nvb ? (nvb - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+        uint32_t any = 0;
+        for (uint32_t t = threadIdx.x; t < mine * per; t += TEAM_WAVES * 64) {
+            const uint32_t sgm = (blockIdx.x + (t / per) * gridDim.x) * per + t % per;
+            if (sgm < a.in_nseg) any |= a.list_count[sgm];
+        }
+        if (!__syncthreads_or((int)any)) {
+            for (uint32_t t = threadIdx.x; t < mine; t += TEAM_WAVES * 64) a.defer_count[blockIdx.x + t * gridDim.x] = 0;
+            return;
+        }
+    }
+    ck::fast_lut_init(lut, threadIdx.x, TEAM_WAVES * 64);
+    ck::fast_lutn_init(lutn, threadIdx.x, TEAM_WAVES * 64);
+    const uint32_t wib = ck::uniform(threadIdx.x >> 6);
+    ck::CanonArgs solo = a;
+    solo.slice_dw = total_dw;
+    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        if (threadIdx.x == 0) *blk_count = 0;
+        __syncthreads();
+        for (uint32_t sgm = vb * a.segs_per_block; sgm < (vb + 1) * a.segs_per_block && sgm < a.in_nseg; ++sgm) {
+            const uint32_t count = a.list_count[sgm];
+            const uint32_t* seg = a.list + (uint64_t)sgm * a.in_seg_cap;
+            for (uint32_t i = 0; i < count; ++i) {
+                const uint32_t entry = seg[i], rec = entry & ck::ENTRY_REC;
+                const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
+                bool done = false;
+                if (len >= 48 && len < (1ull << 31)) {
+                    const uint32_t n = (uint32_t)len;
+                    int why = (entry & ck::ENTRY_NOT_ACGT) ? 1 : 3;
+                    if (why == 3 && ck::need_dw_strand2(n) <= total_dw) { why = ck::canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, TEAM_WAVES); done = why == 0; }
+                    if (why == 1 && ck::need_dw_2n(n) <= total_dw) done = ck::canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, TEAM_WAVES);
+                }
+                if (!done) {
+                    if (wib == 0) {
+                        bool not_acgt = (entry & ck::ENTRY_NOT_ACGT) != 0;
+                        if (!ck::canon_record(solo, rec, lds, lut, lutn, not_acgt)) ck::defer_record(a, blk_count, vb, rec, not_acgt);
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.defer_count[vb] = *blk_count;
+            if (giants && *blk_count) atomicAdd(giants, *blk_count);       // tell the global-scratch kernel there is work
+        }
+    }
+}
+
 // The end of the line: records no LDS tier can hold (2-bit beyond ~640 kb).  Same code, one wave per record, with the
 // packed strands and the candidate bitmask in a slice of GLOBAL scratch instead of LDS.  The lanes of one wavefront
 // hand data to each other through that memory; wave_sync()'s wavefront-scope fences are what the AMDGPU memory model
@@ -615,8 +679,9 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 //                                                             record (canon_core.h team mode): 2-bit up to ~81 kb, few N ~54 kb
 //   B1: 1 wave x 7.4 KiB (18 per CU)                          2-bit up to ~30 kb, with a few N up to ~20.2 kb
 //   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~53 kb, with a few N up to ~35 kb
-//   C: 1 wave x 39 KiB (3 per CU)                             2-bit up to ~160 kb, byte-mode up to ~17 kb
-//   D: 1 wave x 157 KiB (the whole CU)                        2-bit up to ~640 kb, 4-bit up to ~100 kb, byte-mode up to ~70 kb
+//   team stage: 16 waves x 157 KiB (the whole CU)             2-bit up to ~640 kb, few N ~420 kb: the sixteen waves as a team;
+//                                                             4-bit up to ~100 kb, byte-mode up to ~70 kb, ties: wave 0 alone
+//   (single-record calls also use one-wave slices of 39 KiB and 157 KiB: launch_single)
 //   beyond: canon_global_kernel, the same code over slices of a global-memory scratch (one more launch of every batch)
 #ifndef CK_RESCUE_BPC
 #define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
@@ -648,6 +713,10 @@ constexpr int N_TIERS = 5;
 constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40188u : 31996u };     // + 260 dwords of counter and decode table per workgroup
 constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW + ck::FAST_LUTN_DW;        // counter, decode table, N patch table
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
+// a batch runs A, B1, B2 and the 16-wave team stage with the whole LDS (canon_team_kernel); the 39 KiB and 157 KiB one-wave
+// sizes remain for single-record calls (launch_single)
+constexpr int BATCH_TIERS = 4;
+constexpr uint32_t TEAM_SLICE_DW = TIER_D_DW / 16;
 constexpr int N_CU = 256;
 
 }  // namespace
@@ -881,8 +950,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     const bool tiers_idle = c->h_mode[1] == 1;       // the previous batch's tiers found (next to) nothing: small grids for this one
     // (What the idle tiers cost live, measured by not launching them: 82 us of the 3.70 ms headline step, 116 us of uniq's
     // 5.26; with the parallel look at the counts in canon_kernel ~40 us remain -- five dependent launches.)
-    for (int t = 0; t < N_TIERS; ++t) {
-        const bool last = t == N_TIERS - 1;
+    for (int t = 0; t < BATCH_TIERS; ++t) {
+        const bool last = t == BATCH_TIERS - 1;
         const unsigned spb = t <= CK_TIER_KEEP ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
         const unsigned grid = (nseg + spb - 1) / spb;
         a.list = c->d_lists[t + 1]; a.list_count = c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
@@ -891,12 +960,13 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.defer_list = last ? c->d_lists[0] : c->d_lists[t + 2];
         a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 2) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
-        a.slice_dw = TIER_DW[t];
+        a.slice_dw = last ? TEAM_SLICE_DW : TIER_DW[t];
         // `grid` virtual workgroups; launched: a few times what is resident at once (dispatch order balances the rest)
         const unsigned bpc = tiers_idle ? CK_TIER_BPC_IDLE : CK_TIER_BPC;
         const unsigned launched = grid < (unsigned)N_CU * bpc ? grid : (unsigned)N_CU * bpc;
         if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
-        else hipLaunchKernelGGL(canon_kernel<1>, dim3(launched), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, last ? c->d_counters : (uint32_t*)nullptr);
+        else if (last) hipLaunchKernelGGL(canon_team_kernel, dim3(launched), dim3(TEAM_WAVES * 64), (TEAM_WAVES * TEAM_SLICE_DW + TIER_EXTRA_DW) * 4, c->stream, a, grid, c->d_counters);
+        else hipLaunchKernelGGL(canon_kernel<1>, dim3(launched), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
         nseg = grid;
         seg_cap = spb * seg_cap;
     }
@@ -1083,6 +1153,8 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     CK_HIP(c, hipMemcpy(c->d_comp, comp, 256, hipMemcpyHostToDevice));
     CK_HIP(c, hipFuncSetAttribute((const void*)canon_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)((TIER_D_DW + TIER_EXTRA_DW) * 4)));
+    CK_HIP(c, hipFuncSetAttribute((const void*)canon_team_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((TEAM_WAVES * TEAM_SLICE_DW + TIER_EXTRA_DW) * 4)));
     return CIRCKIT_OK;
 }
 
