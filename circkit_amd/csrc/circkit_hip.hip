@@ -83,6 +83,38 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
 // modes, ties, reverse-complement palindromes) is wave 0's alone with the same LDS, as before, the others waiting at the
 // barrier.  a.slice_dw = a sixteenth of the LDS dwords.
 constexpr int TEAM_WAVES = 16;
+// the input segments of virtual workgroup `block`, entry by entry, by all TEAM_WAVES waves of the workgroup; buf: total_dw
+// dwords of LDS -- or of global scratch (canon_global_kernel): the waves of one workgroup share their CU's vector cache,
+// the workgroup barriers between the team's steps order their accesses there as they do in LDS
+__device__ __forceinline__ void team_stage_block(const ck::CanonArgs& a, uint32_t* buf, uint32_t total_dw, const uint32_t* lut, const uint32_t* lutn,
+                                                 uint32_t* blk_count, uint32_t block, uint32_t wib)
+{
+    ck::CanonArgs solo = a;
+    solo.slice_dw = total_dw;
+    for (uint32_t sgm = block * a.segs_per_block; sgm < (block + 1) * a.segs_per_block && sgm < a.in_nseg; ++sgm) {
+        const uint32_t count = a.list_count[sgm];
+        const uint32_t* seg = a.list + (uint64_t)sgm * a.in_seg_cap;
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t entry = seg[i], rec = entry & ck::ENTRY_REC;
+            const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
+            bool done = false;
+            if (len >= 48 && len < (1ull << 31)) {
+                const uint32_t n = (uint32_t)len;
+                int why = (entry & ck::ENTRY_NOT_ACGT) ? 1 : 3;
+                if (why == 3 && ck::need_dw_strand2(n) <= total_dw) { why = ck::canon_record_team2(a, rec, buf, lut, blk_count + 1, wib, TEAM_WAVES); done = why == 0; }
+                if (why == 1 && ck::need_dw_2n(n) <= total_dw) done = ck::canon_record_team2n(a, rec, buf, lut, lutn, blk_count + 1, wib, TEAM_WAVES);
+            }
+            if (!done) {
+                // not the team's: wave 0 alone with the same buffer, the general routine; the others wait
+                if (wib == 0) {
+                    bool not_acgt = (entry & ck::ENTRY_NOT_ACGT) != 0;
+                    if (!ck::canon_record(solo, rec, buf, lut, lutn, not_acgt)) ck::defer_record(a, blk_count, block, rec, not_acgt);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(TEAM_WAVES * 64) void canon_team_kernel(ck::CanonArgs a, uint32_t nvb, uint32_t* giants)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -106,33 +138,10 @@ __global__ __launch_bounds__(TEAM_WAVES * 64) void canon_team_kernel(ck::CanonAr
     ck::fast_lut_init(lut, threadIdx.x, TEAM_WAVES * 64);
     ck::fast_lutn_init(lutn, threadIdx.x, TEAM_WAVES * 64);
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
-    ck::CanonArgs solo = a;
-    solo.slice_dw = total_dw;
     for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
-        for (uint32_t sgm = vb * a.segs_per_block; sgm < (vb + 1) * a.segs_per_block && sgm < a.in_nseg; ++sgm) {
-            const uint32_t count = a.list_count[sgm];
-            const uint32_t* seg = a.list + (uint64_t)sgm * a.in_seg_cap;
-            for (uint32_t i = 0; i < count; ++i) {
-                const uint32_t entry = seg[i], rec = entry & ck::ENTRY_REC;
-                const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
-                bool done = false;
-                if (len >= 48 && len < (1ull << 31)) {
-                    const uint32_t n = (uint32_t)len;
-                    int why = (entry & ck::ENTRY_NOT_ACGT) ? 1 : 3;
-                    if (why == 3 && ck::need_dw_strand2(n) <= total_dw) { why = ck::canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, TEAM_WAVES); done = why == 0; }
-                    if (why == 1 && ck::need_dw_2n(n) <= total_dw) done = ck::canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, TEAM_WAVES);
-                }
-                if (!done) {
-                    if (wib == 0) {
-                        bool not_acgt = (entry & ck::ENTRY_NOT_ACGT) != 0;
-                        if (!ck::canon_record(solo, rec, lds, lut, lutn, not_acgt)) ck::defer_record(a, blk_count, vb, rec, not_acgt);
-                    }
-                    __syncthreads();
-                }
-            }
-        }
+        team_stage_block(a, lds, total_dw, lut, lutn, blk_count, vb, wib);
         __syncthreads();
         if (threadIdx.x == 0) {
             a.defer_count[vb] = *blk_count;
@@ -150,20 +159,23 @@ __global__ __launch_bounds__(TEAM_WAVES * 64) void canon_team_kernel(ck::CanonAr
 // ticket) takes all output segments with the WHOLE scratch -- by then nobody else uses it.  The hand-over of the
 // lists between workgroups follows the agent-scope release / acquire recipe (cdna_hip_programming.md, Guideline 16):
 // stores drained, release fence, ticket; the last arriver acquires before it reads.  a2 = the arguments of phase 2.
-__global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::CanonArgs a2, uint32_t* scratch, uint32_t* ticket, const uint32_t* giants,
-                                                          const uint32_t* tiers_busy, uint32_t* hint_out)
+// Sixteen waves per workgroup: a record whose 2-bit strand (with a few N: + bitmask) fits the slice is the team's, as in
+// canon_team_kernel, with the scratch slice in place of the LDS (a 100 Mb record: one wave took 0.29 s); the rest is wave 0's.
+__global__ __launch_bounds__(TEAM_WAVES * 64) void canon_global_kernel(ck::CanonArgs a, ck::CanonArgs a2, uint32_t* scratch, uint32_t* ticket, const uint32_t* giants,
+                                                                       const uint32_t* tiers_busy, uint32_t* hint_out)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *hint_out = *tiers_busy ? 2u : 1u;     // pinned host word: 1 = the tiers idled, 2 = they worked
     if (*giants == 0) return;           // nothing came out of the last LDS tier (every ordinary batch): the launch costs ~3 us, not ~12
-    __shared__ uint32_t blk_count, lut[ck::FAST_LUT_DW], lutn[ck::FAST_LUTN_DW], last;
-    ck::fast_lut_init(lut, threadIdx.x, 64);
-    ck::fast_lutn_init(lutn, threadIdx.x, 64);
-    if (threadIdx.x == 0) blk_count = 0;
+    __shared__ uint32_t blk_count[4], lut[ck::FAST_LUT_DW], lutn[ck::FAST_LUTN_DW], last;
+    ck::fast_lut_init(lut, threadIdx.x, TEAM_WAVES * 64);
+    ck::fast_lutn_init(lutn, threadIdx.x, TEAM_WAVES * 64);
+    const uint32_t wib = ck::uniform(threadIdx.x >> 6);
+    if (threadIdx.x == 0) blk_count[0] = 0;
     __syncthreads();
-    ck::canon_wave_loop(a, scratch + (size_t)blockIdx.x * a.slice_dw, lut, &blk_count, blockIdx.x, gridDim.x, 0, 1, lutn);
+    team_stage_block(a, scratch + (size_t)blockIdx.x * a.slice_dw, a.slice_dw, lut, lutn, blk_count, blockIdx.x, wib);
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.defer_count[blockIdx.x] = blk_count;
+        a.defer_count[blockIdx.x] = blk_count[0];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -177,9 +189,9 @@ __global__ __launch_bounds__(64) void canon_global_kernel(ck::CanonArgs a, ck::C
     }
     __syncthreads();
     if (!last) return;
-    if (threadIdx.x == 0) blk_count = 0;
+    if (threadIdx.x == 0) blk_count[0] = 0;
     __syncthreads();
-    ck::canon_wave_loop(a2, scratch, lut, &blk_count, 0, 1, 0, 1, lutn);     // no output list: leftovers are counted in status[0]
+    team_stage_block(a2, scratch, a2.slice_dw, lut, lutn, blk_count, 0, wib);     // no output list: leftovers are counted in status[0]
 }
 
 // one record in global scratch (the host API's single-record calls)
@@ -990,7 +1002,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a2.in_nseg = w1; a2.in_seg_cap = spb1 * seg_cap; a2.segs_per_block = w1;
         a2.defer_list = nullptr; a2.defer_count = nullptr; a2.out_seg_cap = 0;
         a2.slice_dw = (uint32_t)(cap_dw < 0xFFFFFFFFull ? cap_dw : 0xFFFFFFFFull);
-        hipLaunchKernelGGL(canon_global_kernel, dim3(w1), dim3(64), 0, c->stream, a, a2, c->d_gscratch, c->d_counters + 2, (const uint32_t*)c->d_counters,
+        hipLaunchKernelGGL(canon_global_kernel, dim3(w1), dim3(TEAM_WAVES * 64), 0, c->stream, a, a2, c->d_gscratch, c->d_counters + 2, (const uint32_t*)c->d_counters,
                            (const uint32_t*)(c->d_counters + 1), c->d_mode + 1);
     }
     if (d_hash) {
@@ -1084,7 +1096,7 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
         max_len = len > max_len ? len : max_len;
     }
     if (max_len >> 31) return fail(c, CIRCKIT_ERR_TOO_LONG, "a record of 2^31 symbols or more (cyclic positions are 32-bit)");
-    if (n == 1) {
+    if (n == 1 && (max_len + 15) / 16 + 2 <= TIER_DW[0]) {     // (a longer record is worth the batch pipeline: its team stages)
         rc = launch_single(c, c->d_in, c->d_off, max_len, need_bytes ? c->d_out : nullptr, idx ? c->d_idx : nullptr,
                            strand ? c->d_strand : nullptr, hash ? c->d_hash : nullptr, flags);
     } else {
