@@ -6,7 +6,8 @@ usage: python tools/gpu_fuzz.py [seed] [records] [profile]   (profile "long": mo
 two-words-per-lane build of the streaming kernel; "nrich": half of the records carry N / '-' -- the batch's mode gets
 MODE_ALPHA: 4-bit register routine in the streaming kernel and the rescue pass; "longn": records of 1..9 kb with a few
 N -- the 2-bit-with-N-mask mode of the LDS tiers and its fallbacks; "prefixn": records of 0.4..6 kb without A except for
-planted A-runs followed by N / G / T / C, on both strands -- an N inside the minimal window and near-ties around it)"""
+planted A-runs followed by N / G / T / C, on both strands -- an N inside the minimal window and near-ties around it;
+"team": records of 15..700 kb -- the multi-wave team modes and their fallbacks)"""
 import os
 import sys
 import time
@@ -46,7 +47,28 @@ if profile == "prefixn":
                 motif = motif.translate(comp)[::-1]
             bg[sp:sp + len(motif)] = motif
         seqs.append(bytes(bg))
-for i in range(0 if profile == "prefixn" else count):
+if profile == "team":
+    # 15..700 kb: the team modes (four waves in tier A, sixteen in the last LDS stage) and what they leave to the general
+    # routine -- a few N, tandem repeats, reverse-complement palindromes, gaps
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for i in range(count):
+        k = rng.integers(0, 100)
+        L = int(rng.integers(15_000, 130_000)) if k < 85 else int(rng.integers(130_000, 700_000))
+        m = rng.integers(0, 100)
+        if m < 8:
+            unit = rand(int(rng.integers(300, 3000))).tobytes()
+            s = (unit * (L // len(unit) + 1))[:L]
+        elif m < 12:
+            half = rand(L // 2).tobytes()
+            s = half + half.translate(comp)[::-1]
+        else:
+            a = rand(L)
+            if m < 45:
+                for _ in range(int(rng.integers(1, 40))):
+                    a[int(rng.integers(0, L))] = ord("N") if rng.random() < 0.9 else ord("-")
+            s = a.tobytes()
+        seqs.append(s)
+for i in range(0 if profile in ("prefixn", "team") else count):
     k = rng.integers(0, 100)
     if profile == "longn":
         L = int(rng.integers(1009, 9000)) if k < 90 else int(rng.integers(48, 1009))
