@@ -50,9 +50,13 @@ struct CanonArgs {
     const uint8_t* comp_lut;     // 256-entry complement table (bio 1.3.1 semantics)
     uint32_t slice_dw;           // LDS dwords available to one wave
     uint32_t flags;              // CK_FLAG_*
+    uint32_t leave_above;        // CK_FLAG_TEAM_BEHIND: see there
 };
 constexpr uint32_t CK_FLAG_BYTES_OPTIONAL = 2u;   // out_bytes is a scratch: only records whose hash is NOT fused need their bytes
 constexpr uint32_t CK_FLAG_FWD_ONLY = 1u;   // lmsr(): forward strand only (lib/src/canonicalize.rs:41-47)
+// a one-wave tier in front of the 16-wave team stage: a record that is pure ACGT as far as anybody knows and longer than
+// leave_above symbols is left for the team (sixteen waves on it instead of one of the three or four this tier runs per CU)
+constexpr uint32_t CK_FLAG_TEAM_BEHIND = 4u;
 
 struct RotResult { uint32_t idx; uint32_t period; };
 struct Lcp { uint32_t k; int cmp; };
@@ -768,9 +772,11 @@ CK_DEV void build_extension2(uint32_t* Ef, uint32_t n)      // lanes 0..2 of one
         Ef[nwv + e] = r ? funnel(Ef[e], Ef[e + 1], (16 - r) * 2) : Ef[e];
     }
 }
-// one strand: minimal key M, how many valid positions own it (2 or more: not unique), the smallest of them
+// one strand: minimal key M, how many valid positions own it, the smallest of them -- and what this lane knows about the
+// owners (team_settle)
+struct TeamOwn { uint32_t M, owners, pos, lane_word, lane_mask; };
 template <bool RCV>
-CK_DEV void team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, uint32_t team, uint32_t* comm, uint32_t& M, uint32_t& owners, uint32_t& pos)
+CK_DEV TeamOwn team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, uint32_t team, uint32_t* comm)
 {
     const uint32_t lane = lane_id(), nwv = (n + 15) / 16;
     if (member == 0 && lane == 0) { comm[0] = ~0u; comm[1] = 0; comm[2] = ~0u; }
@@ -784,15 +790,17 @@ CK_DEV void team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, uin
     const uint32_t Mw = wave_min_u32(best);
     if (lane == 0) lds_atomic_min(comm, Mw);
     block_barrier();
-    M = comm[0];
+    TeamOwn r;
+    r.M = comm[0]; r.lane_word = bestw; r.lane_mask = 0;
     uint32_t cnt = 0, p = ~0u;
-    if (ties != 0 && best == M) {
+    if (ties != 0 && best == r.M) {
         if (ties > 1) {
-            cnt = 2;                                            // several of this lane's words hold M
+            cnt = 64;                                           // several of this lane's words hold M: more than the team settles
         } else {
-            uint32_t mask = word_eq_mask<2>(view_word<2, RCV>(E, bestw * 16, n), view_word<2, RCV>(E, (bestw + 1) * 16, n), M);
+            uint32_t mask = word_eq_mask<2>(view_word<2, RCV>(E, bestw * 16, n), view_word<2, RCV>(E, (bestw + 1) * 16, n), r.M);
             const uint32_t valid = n - bestw * 16;
             if (valid < 16) mask &= (1u << valid) - 1u;         // the last word's positions behind the record end repeat word 0's
+            r.lane_mask = mask;
             cnt = (uint32_t)popc32(mask);
             if (mask) p = bestw * 16 + (uint32_t)ffs32(mask);
         }
@@ -800,8 +808,41 @@ CK_DEV void team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, uin
     const uint32_t cw = (uint32_t)wave_sum_u64(cnt), pw = wave_min_u32(p);
     if (lane == 0 && cw) { lds_atomic_add(comm + 1, cw); lds_atomic_min(comm + 2, pw); }
     block_barrier();
-    owners = comm[1]; pos = comm[2];
+    r.owners = comm[1]; r.pos = comm[2];
     block_barrier();                                            // everybody has the answers before the words are reset
+    return r;
+}
+// A minimal key with a few owners -- a homopolymer run of 17 or more is a row of them, and a 600 kb record has one as its
+// minimal key once in a few thousand; the general routine then is one wave with a candidate bitmask that no longer fits
+// the LDS, a millisecond in the global-memory stage.  The owners are taken in ascending order (an LDS atomic min per round)
+// and the smallest rotation kept (lcp_rot: every wave computes the same).  false: too many owners, or two equal rotations
+// (a period): the general routine's.
+constexpr uint32_t TEAM_MAX_OWNERS = 8;
+template <bool RCV>
+CK_DEV bool team_settle(const uint32_t* E, uint32_t n, uint32_t member, uint32_t* comm, TeamOwn& o)
+{
+    if (o.owners == 1) return true;
+    if (o.owners > TEAM_MAX_OWNERS) return false;
+    const uint32_t lane = lane_id(), base = o.lane_word * 16;
+    uint32_t best = o.pos, last = o.pos;
+    for (uint32_t k = 1; k < o.owners; ++k) {
+        if (member == 0 && lane == 0) comm[2] = ~0u;
+        block_barrier();
+        uint32_t m = o.lane_mask;                               // this lane's owners behind `last`
+        if (m && last >= base) m = last - base >= 15 ? 0u : m & ~((2u << (last - base)) - 1u);
+        const uint32_t pw = wave_min_u32(m ? base + (uint32_t)ffs32(m) : ~0u);
+        if (lane == 0 && pw != ~0u) lds_atomic_min(comm + 2, pw);
+        block_barrier();
+        const uint32_t nxt = comm[2];
+        block_barrier();
+        if (nxt == ~0u) return false;
+        const Lcp c = lcp_rot<2, RCV, RCV>(E, E, best, nxt, n);
+        if (c.k >= n) return false;
+        if (c.cmp > 0) best = nxt;
+        last = nxt;
+    }
+    o.pos = best;
+    return true;
 }
 // lds: the workgroup's slices (team * slice_dw dwords); comm: three LDS words
 // returns 0: done; 1: a byte outside ACGT; 2: a tie / equal strands (the general routine's business)
@@ -820,15 +861,19 @@ CK_DEV int canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, c
     block_barrier();                                            // (also: comm[0] has been read by everybody)
     if (not_acgt) return 1;
     const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
-    uint32_t MF, oF, pF, MC = ~0u, oC = 1, pC = 0;
-    team_scan_locate<false>(E, n, member, team, comm, MF, oF, pF);
-    if (!fwd_only) team_scan_locate<true>(E, n, member, team, comm, MC, oC, pC);
-    // lib/src/canonicalize.rs:58-62: forward only if strictly smaller; equal minimal keys need the full comparison, a
-    // minimal key with several owners the duel: both are the one-wave tiers' business
-    if (!fwd_only && MF == MC) return 2;
-    const bool fwd = fwd_only || MF < MC;
-    if ((fwd ? oF : oC) != 1) return 2;
-    if (!fwd && a.out_index && oF != 1) return 2;          // the reference-visible index counts from the forward minimum
+    TeamOwn F = team_scan_locate<false>(E, n, member, team, comm), C = F;
+    if (!fwd_only) C = team_scan_locate<true>(E, n, member, team, comm);
+    // lib/src/canonicalize.rs:58-62: forward only if strictly smaller.  Equal minimal keys: the two rotations are compared
+    // in full; a minimal key with a few owners: the smallest of their rotations.  More owners, periods: the general routine.
+    bool fwd = fwd_only || F.M < C.M;
+    if (!fwd_only && F.M == C.M) {
+        if (!team_settle<false>(E, n, member, comm, F) || !team_settle<true>(E, n, member, comm, C)) return 2;
+        fwd = lcp_rot<2, false, true>(E, E, F.pos, C.pos, n).cmp < 0;
+    } else {
+        if (!(fwd ? team_settle<false>(E, n, member, comm, F) : team_settle<true>(E, n, member, comm, C))) return 2;
+        if (!fwd && a.out_index && !team_settle<false>(E, n, member, comm, F)) return 2;     // the reference-visible index counts from the forward minimum
+    }
+    const uint32_t pF = F.pos, pC = C.pos;
     const uint32_t idx = fwd ? pF : pC;
     if (a.out_bytes) {
         uint8_t* out = a.out_bytes + off;
@@ -872,9 +917,10 @@ CK_DEV bool canon_record_team2n(const CanonArgs& a, uint64_t rec, uint32_t* lds,
         return (uint32_t)(s0 + ((s0 >> 31) & (int32_t)n));
     };
     const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
-    uint32_t MF, oF, pF, MC = ~0u, oC = 1, pC = 0;
-    team_scan_locate<false>(E, n, member, team, comm, MF, oF, pF);
-    if (!fwd_only) team_scan_locate<true>(E, n, member, team, comm, MC, oC, pC);
+    const TeamOwn F = team_scan_locate<false>(E, n, member, team, comm);
+    TeamOwn C = F;
+    if (!fwd_only) C = team_scan_locate<true>(E, n, member, team, comm);
+    const uint32_t MF = F.M, oF = F.owners, pF = F.pos, MC = fwd_only ? ~0u : C.M, oC = fwd_only ? 1u : C.owners, pC = C.pos;
     if (!fwd_only && MF == MC) return false;
     const bool fwd = fwd_only || MF < MC;
     if ((fwd ? oF : oC) != 1) return false;
@@ -998,7 +1044,8 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
         for (uint32_t i = wib; i < count; i += wpb) {
             const uint32_t rec = seg[i] & ENTRY_REC;
             bool not_acgt = (seg[i] & ENTRY_NOT_ACGT) != 0;
-            if (!canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
+            const bool leave = (a.flags & CK_FLAG_TEAM_BEHIND) && !not_acgt && a.offsets[rec + 1] - a.offsets[rec] > a.leave_above;
+            if (leave || !canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
             wave_sync();
         }
     }

@@ -691,9 +691,11 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 //                                                             record (canon_core.h team mode): 2-bit up to ~81 kb, few N ~54 kb
 //   B1: 1 wave x 7.4 KiB (18 per CU)                          2-bit up to ~30 kb, with a few N up to ~20.2 kb
 //   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~53 kb, with a few N up to ~35 kb
+//   C: 1 wave x 39 KiB (3 per CU)                             4-bit up to ~35 kb, byte-mode up to ~17 kb, tied 2-bit up to ~106 kb
+//                                                             (pure-ACGT records beyond B2's ~53 kb are left to the team stage)
 //   team stage: 16 waves x 157 KiB (the whole CU)             2-bit up to ~640 kb, few N ~420 kb: the sixteen waves as a team;
 //                                                             4-bit up to ~100 kb, byte-mode up to ~70 kb, ties: wave 0 alone
-//   (single-record calls also use one-wave slices of 39 KiB and 157 KiB: launch_single)
+//   (single-record calls also use a one-wave slice of 157 KiB: launch_single)
 //   beyond: canon_global_kernel, the same code over slices of a global-memory scratch (one more launch of every batch)
 #ifndef CK_RESCUE_BPC
 #define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
@@ -725,9 +727,11 @@ constexpr int N_TIERS = 5;
 constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40188u : 31996u };     // + 260 dwords of counter and decode table per workgroup
 constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW + ck::FAST_LUTN_DW;        // counter, decode table, N patch table
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
-// a batch runs A, B1, B2 and the 16-wave team stage with the whole LDS (canon_team_kernel); the 39 KiB and 157 KiB one-wave
-// sizes remain for single-record calls (launch_single)
-constexpr int BATCH_TIERS = 4;
+// a batch runs A, B1, B2, C and -- in place of the one-wave 157 KiB tier, which remains for single-record calls
+// (launch_single) -- the 16-wave team stage with the whole LDS (canon_team_kernel).  Tier C leaves the long pure-ACGT
+// records to the team (CK_FLAG_TEAM_BEHIND); what it keeps is the 4-bit / byte-mode / tied records of 12..35 kb, which
+// without it would be wave 0's alone in the team stage (BASELINE config 4 with 1 % N: 3.7 -> 4.4 ms, measured).
+constexpr int BATCH_TIERS = 5;
 constexpr uint32_t TEAM_SLICE_DW = TIER_D_DW / 16;
 constexpr int N_CU = 256;
 
@@ -973,6 +977,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 2) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
         a.slice_dw = last ? TEAM_SLICE_DW : TIER_DW[t];
+        a.flags = t == BATCH_TIERS - 2 ? flags | ck::CK_FLAG_TEAM_BEHIND : flags;
+        a.leave_above = (TIER_DW[2] - 2) * 16;                  // beyond tier B2's 2-bit strand
         // `grid` virtual workgroups; launched: a few times what is resident at once (dispatch order balances the rest)
         const unsigned bpc = tiers_idle ? CK_TIER_BPC_IDLE : CK_TIER_BPC;
         const unsigned launched = grid < (unsigned)N_CU * bpc ? grid : (unsigned)N_CU * bpc;

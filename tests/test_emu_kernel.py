@@ -377,8 +377,9 @@ def test_team_mode_four_waves_one_record():
     """Records too long for one wave's slice (here 120 dwords: 1888 bases) and short enough for the workgroup's four
     slices together (7648) are canonicalized by the four waves as a team: rows dealt in turn, minimal key / owners /
     position joined through three LDS words.  Lengths around the row (1024 bases) and word boundaries, both strands,
-    rotation index and strand; a tandem repeat (tied minimal key) and a reverse-complement palindrome (equal strands)
-    are left untouched for the tiers behind."""
+    rotation index and strand; a reverse-complement palindrome (equal minimal keys on both strands) and a minimal
+    16-mer with a few owners (twice, a homopolymer run, an imperfect repeat) are settled by the team, a true tandem
+    repeat is left untouched for the tiers behind."""
     rng = np.random.default_rng(1500)
     comp = bytes.maketrans(b"ACGT", b"TGCA")
     seqs = []
@@ -388,7 +389,13 @@ def test_team_mode_four_waves_one_record():
     half = seqsets.random_mixed(1502, 1, 1500, 1500)[0]
     withn = bytearray(seqsets.random_mixed(1503, 1, 4000, 4000)[0]); withn[2500] = ord("N")
     seqs.append(bytes(withn))                          # one N: the N-mask team (canon_record_team2n) has it
-    odd = [(unit * 5)[:4000], half + half.translate(comp)[::-1]]
+    seqs.append(half + half.translate(comp)[::-1])     # equal minimal keys on the two strands: settled by a full comparison
+    twice = bytearray(seqsets.random_mixed(1504, 1, 5000, 5000)[0].replace(b"AAAA", b"ACAC"))
+    twice[99:120] = b"C" + b"A" * 16 + b"CGTC"; twice[2999:3020] = b"T" + b"A" * 16 + b"CGTG"      # the minimal 16-mer twice: the smaller rotation
+    seqs.append(bytes(twice))
+    seqs.append((unit * 5)[:4000])                     # four or five owners of the minimal key, no period: the smallest rotation
+    seqs.append(b"C" + b"A" * 19 + seqsets.random_mixed(1505, 1, 3000, 3000)[0].replace(b"AAAA", b"ACAC"))     # a homopolymer run: a row of owners
+    odd = [unit * 4]                                   # a true period (3908 = 4 x 977): the general routine's
     seqs += odd
     data, offs = seqsets.pack(seqs)
     want = [seqsets.expected(O, s) for s in seqs]
