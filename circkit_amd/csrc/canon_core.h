@@ -50,13 +50,10 @@ struct CanonArgs {
     const uint8_t* comp_lut;     // 256-entry complement table (bio 1.3.1 semantics)
     uint32_t slice_dw;           // LDS dwords available to one wave
     uint32_t flags;              // CK_FLAG_*
-    uint32_t leave_above;        // CK_FLAG_TEAM_BEHIND: see there
 };
 constexpr uint32_t CK_FLAG_BYTES_OPTIONAL = 2u;   // out_bytes is a scratch: only records whose hash is NOT fused need their bytes
 constexpr uint32_t CK_FLAG_FWD_ONLY = 1u;   // lmsr(): forward strand only (lib/src/canonicalize.rs:41-47)
-// a one-wave tier in front of the 16-wave team stage: a record that is pure ACGT as far as anybody knows and longer than
-// leave_above symbols is left for the team (sixteen waves on it instead of one of the three or four this tier runs per CU)
-constexpr uint32_t CK_FLAG_TEAM_BEHIND = 4u;
+
 
 struct RotResult { uint32_t idx; uint32_t period; };
 struct Lcp { uint32_t k; int cmp; };
@@ -1044,8 +1041,7 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
         for (uint32_t i = wib; i < count; i += wpb) {
             const uint32_t rec = seg[i] & ENTRY_REC;
             bool not_acgt = (seg[i] & ENTRY_NOT_ACGT) != 0;
-            const bool leave = (a.flags & CK_FLAG_TEAM_BEHIND) && !not_acgt && a.offsets[rec + 1] - a.offsets[rec] > a.leave_above;
-            if (leave || !canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
+            if (!canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
             wave_sync();
         }
     }
@@ -1054,7 +1050,8 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
 // Team pass of a workgroup over the deferral segment it has just written (every wave, behind a workgroup barrier):
 // entries the team can take (team_takes, pure ACGT as far as anybody knows) are canonicalized by all waves together and
 // leave the segment, the others move up.  blk_count[0] = entries, blk_count[1..3] = the team's three words.
-CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, uint32_t* blk_count, uint32_t block, uint32_t wib, uint32_t wpb)
+CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, uint32_t* blk_count, uint32_t block, uint32_t wib, uint32_t wpb,
+                      bool allow_solo = true)
 {
     const uint32_t cnt = *blk_count;
     if (cnt == 0 || !a.defer_list) return;
@@ -1070,6 +1067,20 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, co
             int why = (entry & ENTRY_NOT_ACGT) ? 1 : 3;            // 3: not tried
             if (why == 3 && team_takes((uint32_t)len, a.slice_dw, wpb)) { why = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb); done = why == 0; }
             if (why == 1 && lutn && team_takes_2n((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, wpb);
+        }
+        if (!done && lutn && allow_solo) {
+            // not the team's (4-bit and byte modes, periods): wave 0 alone with the workgroup's whole LDS, the general
+            // routine -- what a one-wave tier with a slice of that size would do, without a launch of its own
+            CanonArgs solo = a;
+            solo.slice_dw = wpb * a.slice_dw;
+            if (wib == 0) {
+                bool na = (entry & ENTRY_NOT_ACGT) != 0;
+                const bool ok = canon_record(solo, rec, lds, lut, lutn, na);
+                if (lane_id() == 0) blk_count[1] = ok ? 1u : 0u;
+            }
+            block_barrier();
+            done = blk_count[1] != 0;
+            block_barrier();
         }
         if (!done) {
             if (wib == 0 && lane_id() == 0 && kept != k) seg[kept] = entry;

@@ -683,20 +683,17 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS tiers of the general kernel (dwords per wave; + 276 dwords per workgroup: deferral counter, decode table, N patch
-// table).  A 2-bit record needs its ONE stored strand, n / 16 + 2 dwords (+ n / 32 for the candidate bitmask only if the
-// minimal key ties); with a few N the strand + n / 32 of N bitmask; 4-bit and byte mode two strands + the bitmask.
-//   A: 4 waves x 5 KiB per workgroup (7 workgroups per CU)    2-bit records up to ~20.4 kb: all of BASELINE config 4
-//   A (cont.)                                                 ... with a few N up to ~13.6 kb; the four waves as a TEAM on one
-//                                                             record (canon_core.h team mode): 2-bit up to ~81 kb, few N ~54 kb
-//   B1: 1 wave x 7.4 KiB (18 per CU)                          2-bit up to ~30 kb, with a few N up to ~20.2 kb
-//   B2: 1 wave x 13 KiB (11 per CU)                           2-bit up to ~53 kb, with a few N up to ~35 kb
-//   C: 1 wave x 39 KiB (3 per CU)                             4-bit up to ~35 kb, byte-mode up to ~17 kb, tied 2-bit up to ~106 kb
-//                                                             (pure-ACGT records beyond B2's ~53 kb are left to the team stage)
-//   team stage: 16 waves x 157 KiB (the whole CU)             2-bit up to ~640 kb, few N ~420 kb: the sixteen waves as a team;
-//                                                             4-bit up to ~100 kb, byte-mode up to ~70 kb, ties: wave 0 alone
-//   (single-record calls also use a one-wave slice of 157 KiB: launch_single)
-//   beyond: canon_global_kernel, the same code over slices of a global-memory scratch (one more launch of every batch)
+// LDS stages of a batch behind the rescue pass (+ 276 dwords per workgroup: deferral counter, decode table, N patch table).
+// A 2-bit record needs its ONE stored strand, n / 16 + 2 dwords (+ n / 32 for the candidate bitmask only if the minimal key
+// ties); with a few N the strand + n / 32 of N bitmask; 4-bit and byte mode two strands + the bitmask.  In every stage a
+// record goes to ONE wave if it fits that wave's slice, to the workgroup's waves as a TEAM if it is 2-bit material and fits
+// their slices together, else to wave 0 ALONE with the workgroup's whole LDS (canon_core.h team_pass, canon_team_kernel).
+//   A: 4 waves x 5 KiB (7 workgroups per CU)      one wave: 2-bit up to ~20.4 kb (all of BASELINE config 4), few N ~13.6 kb,
+//                                                 4-bit ~4.5 kb; team: 2-bit ~81 kb, few N ~54 kb; alone: 4-bit ~18 kb
+//   C: 4 waves x 9.7 KiB (4 workgroups per CU)    team: 2-bit up to ~160 kb, few N ~106 kb; alone: 4-bit ~35 kb, bytes ~17 kb
+//   team stage: 16 waves x 157 KiB (the CU)       team: 2-bit up to ~640 kb, few N ~420 kb; alone: 4-bit ~100 kb, bytes ~70 kb
+//   beyond: canon_global_kernel, the same over slices of a global-memory scratch (one more launch of every batch)
+// (One-wave slices of 7.4 / 13 / 39 / 157 KiB -- stages of their own in earlier versions -- remain for single-record calls.)
 #ifndef CK_RESCUE_BPC
 #define CK_RESCUE_BPC 8      // workgroups per CU of the rescue pass's persistent grid
 #endif
@@ -727,11 +724,13 @@ constexpr int N_TIERS = 5;
 constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40188u : 31996u };     // + 260 dwords of counter and decode table per workgroup
 constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW + ck::FAST_LUTN_DW;        // counter, decode table, N patch table
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
-// a batch runs A, B1, B2, C and -- in place of the one-wave 157 KiB tier, which remains for single-record calls
-// (launch_single) -- the 16-wave team stage with the whole LDS (canon_team_kernel).  Tier C leaves the long pure-ACGT
-// records to the team (CK_FLAG_TEAM_BEHIND); what it keeps is the 4-bit / byte-mode / tied records of 12..35 kb, which
-// without it would be wave 0's alone in the team stage (BASELINE config 4 with 1 % N: 3.7 -> 4.4 ms, measured).
-constexpr int BATCH_TIERS = 5;
+// A batch's LDS stages: A (four waves x 5 KiB), C (four waves x 9.7 KiB) and the team stage (sixteen waves, the whole LDS).
+// In each of them a record goes to one wave if it fits that wave's slice, to all waves of the workgroup as a team if it is
+// 2-bit material and fits their slices together, else to wave 0 alone with the workgroup's whole LDS (canon_core.h
+// team_pass, canon_team_kernel) -- which is what the one-wave tiers B1 / B2 / C / D of 7.4 / 13 / 39 / 157 KiB did with a
+// launch each; those sizes remain for single-record calls (launch_single).
+constexpr int BATCH_TIERS = 3;
+constexpr uint32_t BATCH_SLICE_DW[BATCH_TIERS - 1] = { CK_TIER_A, 9980 / 4 };
 constexpr uint32_t TEAM_SLICE_DW = TIER_D_DW / 16;
 constexpr int N_CU = 256;
 
@@ -968,7 +967,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     // 5.26; with the parallel look at the counts in canon_kernel ~40 us remain -- five dependent launches.)
     for (int t = 0; t < BATCH_TIERS; ++t) {
         const bool last = t == BATCH_TIERS - 1;
-        const unsigned spb = t <= CK_TIER_KEEP ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
+        const unsigned spb = t == 0 ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
         const unsigned grid = (nseg + spb - 1) / spb;
         a.list = c->d_lists[t + 1]; a.list_count = c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb;
@@ -976,15 +975,12 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         a.defer_list = last ? c->d_lists[0] : c->d_lists[t + 2];
         a.defer_count = last ? c->d_seg_counts : c->d_seg_counts + (uint64_t)(t + 2) * c->seg_alloc;
         a.out_seg_cap = spb * seg_cap;
-        a.slice_dw = last ? TEAM_SLICE_DW : TIER_DW[t];
-        a.flags = t == BATCH_TIERS - 2 ? flags | ck::CK_FLAG_TEAM_BEHIND : flags;
-        a.leave_above = (TIER_DW[2] - 2) * 16;                  // beyond tier B2's 2-bit strand
+        a.slice_dw = last ? TEAM_SLICE_DW : BATCH_SLICE_DW[t];
         // `grid` virtual workgroups; launched: a few times what is resident at once (dispatch order balances the rest)
         const unsigned bpc = tiers_idle ? CK_TIER_BPC_IDLE : CK_TIER_BPC;
         const unsigned launched = grid < (unsigned)N_CU * bpc ? grid : (unsigned)N_CU * bpc;
-        if (t == 0) hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
-        else if (last) hipLaunchKernelGGL(canon_team_kernel, dim3(launched), dim3(TEAM_WAVES * 64), (TEAM_WAVES * TEAM_SLICE_DW + TIER_EXTRA_DW) * 4, c->stream, a, grid, c->d_counters);
-        else hipLaunchKernelGGL(canon_kernel<1>, dim3(launched), dim3(64), (TIER_DW[t] + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
+        if (last) hipLaunchKernelGGL(canon_team_kernel, dim3(launched), dim3(TEAM_WAVES * 64), (TEAM_WAVES * TEAM_SLICE_DW + TIER_EXTRA_DW) * 4, c->stream, a, grid, c->d_counters);
+        else hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * a.slice_dw + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
         nseg = grid;
         seg_cap = spb * seg_cap;
     }

@@ -139,14 +139,14 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false; };
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false, solo = true; };
 void wave_body(void* p)          // one fiber of a 4-wave workgroup of the LDS tier (canon_kernel<4>)
 {
     Launch* L = (Launch*)p;
     const uint32_t wib = ck::emu::cur_wave();
     ck::canon_wave_loop(L->a, L->lds + wib * L->a.slice_dw, L->lut, L->blk_count, L->block, L->nblocks, wib, 4, L->lutn);
     ck::block_barrier();
-    ck::team_pass(L->a, L->lds, L->lut, L->lutn, L->blk_count, L->block, wib, 4);
+    ck::team_pass(L->a, L->lds, L->lut, L->lutn, L->blk_count, L->block, wib, 4, L->solo);
 }
 void rescue_body(void* p)
 {
@@ -228,7 +228,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a.status = &status; L.a.comp_lut = comp; L.a.flags = flags;
     L.a.defer_list = list_f.data(); L.a.defer_count = cnt_f.data(); L.a.out_seg_cap = cap;
     L.lds = lds.data(); L.lut = lut; L.lutn = lutn; L.nblocks = G;
-    L.alpha = alpha != 0;        // which builds of the streaming kernel and the rescue pass (launch_canon: MODE_ALPHA of the batch's mode)
+    L.alpha = (alpha & 1) != 0;  // which builds of the streaming kernel and the rescue pass (launch_canon: MODE_ALPHA of the batch's mode)
+    L.solo = (alpha & 2) == 0;   // bit 1: the tier's team pass without its wave-0-alone fallback (tests that pin a mode)
     uint32_t total_f = 0, total_a = 0;
     for (uint32_t b = 0; b < G && !all_records; ++b) {
         uint32_t blk = 0;
@@ -238,7 +239,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     }
     if (all_records) total_f = (uint32_t)n_records;
     L.all_records = all_records;
-    L.alpha = alpha != 0;        // which build of the rescue pass (launch_canon: MODE_ALPHA of the batch's mode)
+    L.alpha = (alpha & 1) != 0;  // which build of the rescue pass (launch_canon: MODE_ALPHA of the batch's mode)
     if (n_fast) *n_fast = (uint32_t)n_records - total_f;
     // rescue pass: the streaming kernel's leftovers that are eligible by themselves (same build choice as launch_canon)
     std::vector<uint32_t> list_r((size_t)G * cap), cnt_r(G, 0);

@@ -61,13 +61,15 @@ def test_deferral_to_bigger_tier():
 def test_tied_minimal_key_without_room_for_the_bitmask_moves_on():
     """The 2-bit tiers admit a record by its strand alone; only a tie of the minimal key needs the candidate bitmask.
     Tandem repeats (every key ties) of 1600 bases: the strand needs 102 dwords, strand + bitmask 153.  A 120-dword
-    slice defers exactly them -- untouched -- and finishes the random records around them; 160 dwords take all."""
+    slice defers exactly them -- untouched -- and finishes the random records around them; 160 dwords take all.  (The
+    tier's team pass then gives them to wave 0 alone with the workgroup's whole LDS: solo=False looks at the tier before.)"""
     rng = np.random.default_rng(33)
     rep = [bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8)) * (1600 // k) for k in (5, 8, 20, 32)]
     rnd = seqsets.random_mixed(34, 6, 1500, 1800)
     seqs = [rnd[0], rep[0], rnd[1], rep[1], rep[2], rnd[2], rnd[3], rep[3], rnd[4], rnd[5]]
-    assert check(seqs, slice_dw=120) == len(rep)
-    assert check(seqs, slice_dw=160) == 0
+    assert check(seqs, slice_dw=120, solo=False) == len(rep)
+    assert check(seqs, slice_dw=160, solo=False) == 0
+    assert check(seqs, slice_dw=120) == 0                 # wave 0 alone with the workgroup's four slices takes them
 
 
 def test_wave_count_independent():
@@ -317,7 +319,8 @@ def test_two_bit_mode_with_n_bitmask_is_the_mode_that_runs():
         seqs.append(bytes(s))
     data, offs = seqsets.pack(seqs)
     want = [seqsets.expected(O, s) for s in seqs]
-    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=400, n_waves=8, alpha=False)
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=400, n_waves=8, alpha=False,
+                                                               solo=False)
     done = 0
     for i, s in enumerate(seqs):
         if strand[i] == 0xFF:                       # an N inside the minimal window, or a tie: left to a tier with room for 4 bits
@@ -354,7 +357,8 @@ def test_n_inside_the_minimal_window_prefix_rule():
     want = [seqsets.expected(O, s) for s in seqs]
     # 100 dwords: room for the 2-bit strand + N bitmask of all of them, for the 4-bit strands of none -- what comes out
     # here came out of canon_record_mode2n; what it refuses is deferred (and checked with a slice that takes everything)
-    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=100, n_waves=8, alpha=False)
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=100, n_waves=8, alpha=False,
+                                                               solo=False)
     assert status == 0
     kept_with_n_in_window = 0
     for i, s in enumerate(seqs):
@@ -399,7 +403,8 @@ def test_team_mode_four_waves_one_record():
     seqs += odd
     data, offs = seqsets.pack(seqs)
     want = [seqsets.expected(O, s) for s in seqs]
-    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False)
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False,
+                                                               solo=False)
     assert status == 0 and ndef == len(odd)
     strands = set()
     for i, s in enumerate(seqs[:-len(odd)]):
@@ -444,7 +449,8 @@ def test_team_mode_with_n_bitmask():
         seqs.append(bytes(bg))
     data, offs = seqsets.pack(seqs)
     want = [seqsets.expected(O, s) for s in seqs]
-    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False)
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False,
+                                                               solo=False)
     assert status == 0
     done = kept_with_n_in_window = 0
     for i, s in enumerate(seqs):
