@@ -994,12 +994,8 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
                 not_acgt = true;
             }
         }
-        // a few N: 2-bit words + a mask strand (0 = done; else the 4-bit mode decides, here or in a bigger tier)
-#ifdef CK_NO_2N
-        if (false) {
-#else
+        // a few N: 2-bit words + an N bitmask (0 = done; else the 4-bit mode decides, here or in a bigger stage)
         if (lutn && need_dw_2n(n) <= a.slice_dw) {
-#endif
             if (canon_record_mode2n(a, rec, src, off, n, lds, lut, lutn) == 0) return true;
             wave_sync();            // every lane has read the strands before the next mode overwrites them
         }

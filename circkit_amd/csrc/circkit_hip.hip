@@ -703,9 +703,6 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #ifndef CK_TIER_BPC_IDLE
 #define CK_TIER_BPC_IDLE 8 // ...when the previous batch left them (next to) nothing to do
 #endif
-#ifndef CK_TIER_KEEP
-#define CK_TIER_KEEP 2     // tiers 0..KEEP keep one list segment per workgroup (full-width grids); later ones merge 4
-#endif
 // A 2-bit record is admitted by its one stored strand alone, (n + 15) / 16 + 2 dwords (the candidate bitmask is only needed
 // on a tie of the minimal key; a record that ties without room for it moves on).  Tier A: 5 KiB per wave = records up to
 // 20.4 kb -- all of BASELINE config 4 in the four-wave tier, 7 workgroups = 28 waves per CU by LDS and by VGPRs alike
