@@ -964,7 +964,9 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     // 5.26; with the parallel look at the counts in canon_kernel ~40 us remain -- five dependent launches.)
     for (int t = 0; t < BATCH_TIERS; ++t) {
         const bool last = t == BATCH_TIERS - 1;
-        const unsigned spb = t == 0 ? 1 : (last ? (nseg + N_CU - 1) / N_CU : 4);
+        // stage C merges four segments per workgroup when there are plenty (its workgroups are four to a CU); a small batch
+        // keeps one segment per workgroup -- 4000 records of 120 kb are 250 segments: 63 workgroups would leave the chip idle
+        const unsigned spb = t == 0 ? 1 : (last ? (nseg + N_CU - 1) / N_CU : (nseg >= 16u * N_CU ? 4 : 1));
         const unsigned grid = (nseg + spb - 1) / spb;
         a.list = c->d_lists[t + 1]; a.list_count = c->d_seg_counts + (uint64_t)(t + 1) * c->seg_alloc;
         a.in_nseg = nseg; a.in_seg_cap = seg_cap; a.segs_per_block = spb;
