@@ -43,6 +43,7 @@ struct CanonArgs {
     const uint32_t* list;        // nullable: input list (nullptr = all records 0..n_records-1, grid-stride)
     const uint32_t* list_count;  // [in_nseg] entries per input segment
     uint32_t in_nseg, in_seg_cap, segs_per_block;   // workgroup b consumes input segments [b*k, b*k + k), k = segs_per_block
+    uint32_t all_seg_cap;        // stages that walk ALL records of a batch (mode 3): segment s = records [s * all_seg_cap, (s + 1) * all_seg_cap)
     uint32_t* defer_list;        // nullable: output list, one segment per workgroup of THIS launch
     uint32_t* defer_count;       // [gridDim.x]
     uint32_t out_seg_cap;

@@ -221,7 +221,7 @@ struct RescueState {        // per-wave constants of the rescue pass (kept acros
 };
 // one wave's share of list segment `seg_index`; failures are appended to the SAME segment index of the output list.
 // all_records: the streaming kernel did not run (a batch with so many long records that hardly any group could be
-// staged): segment s then stands for records [s * in_seg_cap, (s + 1) * in_seg_cap).
+// staged): segment s then stands for records [s * all_seg_cap, (s + 1) * all_seg_cap).
 // The wave takes the segment's entries in chunks of RESCUE_CHUNK; list entries and offsets of a chunk arrive in one
 // round trip (lane L: entry L, handed out by v_readlane), and each record's bytes are requested while the record
 // before it is being processed -- taken one at a time, a record is three dependent round trips (list entry -> offsets ->
@@ -296,10 +296,10 @@ CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, Rescue
                                  uint32_t wib, uint32_t wpb, bool all_records)
 {
     const uint32_t t = lane_id();
-    const uint64_t first = (uint64_t)seg_index * a.in_seg_cap;
-    const uint32_t count = all_records ? (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.in_seg_cap ? a.n_records - first : a.in_seg_cap))
+    const uint64_t first = (uint64_t)seg_index * a.all_seg_cap;          // (all_records only)
+    const uint32_t count = all_records ? (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap))
                                        : a.list_count[seg_index];
-    const uint32_t* seg = a.list + first;
+    const uint32_t* seg = a.list + (uint64_t)seg_index * a.in_seg_cap;
     if constexpr (!ALPHA) {
         // the lean build: one record at a time, pure-ACGT records only (what is left after the streaming kernel of an
         // ordinary batch is a handful of records per segment; prefetching bought nothing there, measured)

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 // waves per workgroup with a tier-A slice each.  A record of 48..1008 bases takes the register routine straight from
 // memory (what the rescue pass did for such a batch), every other record the general LDS routine (what tier A did with the
 // rescue pass's list), so the latency-bound short records and the bandwidth-bound long ones share the CUs instead of
-// following each other in two launches with a list in between.  Segment s = records [s * in_seg_cap, (s + 1) * in_seg_cap);
+// following each other in two launches with a list in between.  Segment s = records [s * all_seg_cap, (s + 1) * all_seg_cap);
 // what the slice cannot hold goes to segment s of the list tier A consumes.  Batches that also want the XXH3 keep the
 // two-launch path: with the fused hash next to the LDS routine this kernel needed ~115 VGPRs (spills at any useful occupancy).
 __global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out,
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::Canon
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
-        const uint64_t first = (uint64_t)sgm * a.in_seg_cap;
-        const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.in_seg_cap ? a.n_records - first : a.in_seg_cap));
+        const uint64_t first = (uint64_t)sgm * a.all_seg_cap;
+        const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap));
         for (uint32_t i = wib; i < count; i += 4) {
             const uint32_t rec = (uint32_t)first + i;
             const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
@@ -835,8 +835,14 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
     const uint64_t per_step = aux ? StreamCAux::GROUP : StreamC::GROUP;    // records a workgroup takes per iteration
     const uint64_t blocks = (n + per_step - 1) / per_step;
-    const unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
+    unsigned G = (unsigned)(blocks < (uint64_t)N_CU * CK_FAST_BPC ? blocks : (uint64_t)N_CU * CK_FAST_BPC);
+    // A small batch gets more segments than the streaming kernel has workgroups with work (the others publish an empty
+    // segment and leave): the stages that walk all records of a mode-3 batch deal them out all_cap at a time, and a list
+    // segment is one workgroup of every stage behind -- 2000 records of 250 kb in 125 segments of 16 left half the chip idle.
+    const unsigned G_small = (unsigned)(n < (uint64_t)N_CU * 16 ? n : (uint64_t)N_CU * 16);
+    if (G < G_small) G = G_small;
     const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
+    const uint32_t all_cap = (uint32_t)((n + G - 1) / G);
     // + 1024 segments of slack: a stage that merges k segments per workgroup addresses up to k - 1 segments past the end
     int rc = ensure_lists(c, (uint64_t)G * cap + 1024ull * cap, G < 256u ? 256u : G);
     if (rc) return rc;
@@ -874,7 +880,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = d_hash; a.hashed = c->d_hashed;
     a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
-    a.list = nullptr; a.list_count = nullptr;
+    a.list = nullptr; a.list_count = nullptr; a.all_seg_cap = all_cap;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
     const uint32_t* counts = c->d_counters + 5;     // the mode word

@@ -244,7 +244,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     // rescue pass: the streaming kernel's leftovers that are eligible by themselves (same build choice as launch_canon)
     std::vector<uint32_t> list_r((size_t)G * cap), cnt_r(G, 0);
     uint32_t total_r = 0;
-    L.a.list = list_f.data(); L.a.list_count = cnt_f.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1;
+    L.a.list = list_f.data(); L.a.list_count = cnt_f.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1; L.a.all_seg_cap = cap;
     L.a.defer_list = list_r.data(); L.a.defer_count = cnt_r.data(); L.a.out_seg_cap = cap;
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;
