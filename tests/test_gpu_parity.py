@@ -187,6 +187,34 @@ def test_team_mode_records_of_20_to_80_kb(ctx, O):
     ctx.use_own_stream()
 
 
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 257, 4095, 4096, 4097, 9000])
+def test_small_batch_segment_geometry(ctx, O, n):
+    """Small batches get more list segments than the streaming kernel has workgroups with work, and the stages that walk
+    ALL records of a mode-3 batch (canon_mixed_kernel; the rescue pass for batches that also want hashes) deal them out
+    all_seg_cap at a time: record counts around the limits (16 per streaming workgroup, 4096 segments), device API, bytes
+    only and bytes + XXH3."""
+    import torch
+    from tests import seqsets
+    seqs = seqsets.random_mixed(300 + n, n, 48, 6000)            # more than one in eight beyond 2032 bases: mode 3
+    data, offs = seqsets.pack(seqs)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    d_out = torch.zeros_like(d_bytes)
+    ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out)
+    assert ctx.batch_status() == 0
+    assert np.array_equal(d_out.cpu().numpy(), exp)
+    d_out.zero_()
+    d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
+    ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash)
+    assert ctx.batch_status() == 0
+    assert np.array_equal(d_out.cpu().numpy(), exp)
+    assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    ctx.use_own_stream()
+
+
 def test_device_api_finishes_long_records_on_the_device(ctx, O):
     """Device API: the batch call enqueues everything, records beyond the LDS tiers included (global-scratch stages);
     any synchronisation with the stream is enough."""
