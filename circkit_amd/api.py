@@ -45,6 +45,10 @@ SIGNATURES = {
     "circkit_uniq_reset": (_i, [_vp, _u64]),
     "circkit_uniq_insert_device": (_i, [_vp, _vp, _u64, _u64]),
     "circkit_uniq_insert_pairs_device": (_i, [_vp, _vp, _vp, _u64]),
+    "circkit_uniq_partition_device": (_i, [_vp, _vp, _u64, _u64, ctypes.c_uint32, _vp, _vp, _vp]),
+    "circkit_uniq_insert_rows_device": (_i, [_vp, _vp, _u64]),
+    "circkit_uniq_lookup_rows_device": (_i, [_vp, _vp, _u64, _vp]),
+    "circkit_uniq_gather_device": (_i, [_vp, _vp, _vp, _u64, _u64, _vp, _vp]),
     "circkit_uniq_lookup_device": (_i, [_vp, _vp, _u64, _vp]),
     "circkit_uniq_status": (_i, [_vp, ctypes.POINTER(_u32)]),
     "circkit_uniq_resolve_device": (_i, [_vp, _vp, _u64, _u64, _vp, _vp]),
@@ -195,6 +199,20 @@ class Context:
 
     def uniq_insert_pairs_device(self, d_hash, d_index, n):
         self._check(self._lib.circkit_uniq_insert_pairs_device(self._h, _ptr(d_hash), _ptr(d_index), int(n)))
+
+    def uniq_partition_device(self, d_hash, n, base_index, world, d_rows, d_counts, d_slot):
+        self._check(self._lib.circkit_uniq_partition_device(self._h, _ptr(d_hash), int(n), int(base_index), int(world), _ptr(d_rows),
+                                                            _ptr(d_counts), _ptr(d_slot)))
+
+    def uniq_insert_rows_device(self, d_rows, n):
+        self._check(self._lib.circkit_uniq_insert_rows_device(self._h, _ptr(d_rows), int(n)))
+
+    def uniq_lookup_rows_device(self, d_rows, n, d_answers):
+        self._check(self._lib.circkit_uniq_lookup_rows_device(self._h, _ptr(d_rows), int(n), _ptr(d_answers)))
+
+    def uniq_gather_device(self, d_answers, d_slot, n, base_index, d_first_seen, d_keep=None):
+        self._check(self._lib.circkit_uniq_gather_device(self._h, _ptr(d_answers), _ptr(d_slot), int(n), int(base_index), _ptr(d_first_seen),
+                                                         _ptr(d_keep)))
 
     def uniq_lookup_device(self, d_hash, n, d_first_seen):
         self._check(self._lib.circkit_uniq_lookup_device(self._h, _ptr(d_hash), int(n), _ptr(d_first_seen)))

@@ -672,6 +672,104 @@ __global__ __launch_bounds__(256) void uniq_rehash_kernel(const UniqSlot* __rest
     }
 }
 
+// ---- multi-GPU exchange (circkit_amd/uniq.py, exchange="partition"): the key space is cut into `world` ranges, a key
+// belongs to rank ((h >> 20) & 0x7FFFFFFF) % world (well-mixed middle bits of the XXH3 output).
+constexpr uint32_t UNIQ_MAX_WORLD = 64;
+__device__ __forceinline__ uint32_t uniq_owner(uint64_t h, uint32_t world) { return (uint32_t)((h >> 20) & 0x7FFFFFFFu) % world; }
+// pass 1: keys per owner (one global atomic per workgroup and owner)
+__global__ __launch_bounds__(256) void uniq_partition_count_kernel(const uint64_t* __restrict__ hash, uint64_t n, uint32_t world, unsigned long long* counts)
+{
+    __shared__ uint32_t hist[UNIQ_MAX_WORLD];
+    if (threadIdx.x < UNIQ_MAX_WORLD) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&hist[uniq_owner(hash[i], world)], 1u);
+    __syncthreads();
+    if (threadIdx.x < world && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+// pass 2: rows[(pos)] = {hash, base + i} with the rows of one owner together (owners in rank order, any order inside),
+// slot[i] = pos.  Each workgroup takes chunks of 256 * 16 keys: a histogram of the chunk, one global atomic per owner to
+// reserve its rows, then every key its place.
+__global__ __launch_bounds__(256) void uniq_partition_scatter_kernel(const uint64_t* __restrict__ hash, uint64_t n, uint64_t base, uint32_t world,
+                                                                     const unsigned long long* __restrict__ counts, unsigned long long* cursor,
+                                                                     uint64_t* rows, uint32_t* slot)
+{
+    __shared__ uint32_t hist[UNIQ_MAX_WORLD];
+    __shared__ unsigned long long start[UNIQ_MAX_WORLD];
+    constexpr uint32_t PER = 16;
+    const uint64_t chunk = 256ull * PER;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < n; c0 += (uint64_t)gridDim.x * chunk) {
+        if (threadIdx.x < UNIQ_MAX_WORLD) hist[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t own[PER], rank[PER];
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint64_t i = c0 + k * 256 + threadIdx.x;
+            own[k] = i < n ? uniq_owner(hash[i], world) : 0xFFFFFFFFu;
+            rank[k] = i < n ? atomicAdd(&hist[own[k]], 1u) : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x < world) {
+            unsigned long long first = 0;
+            for (uint32_t w = 0; w < threadIdx.x; ++w) first += counts[w];              // (world is small)
+            start[threadIdx.x] = first + (hist[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)hist[threadIdx.x]) : 0ull);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PER; ++k) {
+            const uint64_t i = c0 + k * 256 + threadIdx.x;
+            if (i < n) {
+                const uint64_t pos = start[own[k]] + rank[k];
+                typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<v2*>(rows + 2 * pos) = v2{ hash[i], base + i };
+                slot[i] = (uint32_t)pos;
+            }
+        }
+        __syncthreads();
+    }
+}
+// rows of {hash, global index}: fold them into the table / answer each with the smallest index seen for its hash
+__global__ __launch_bounds__(256) void uniq_insert_rows_kernel(const uint64_t* __restrict__ rows, uint64_t n, UniqSlot* t, uint64_t mask, uint32_t* status)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const UniqSlot r = uniq_peek(reinterpret_cast<const UniqSlot*>(rows) + i);
+        if (!uniq_fold(t, mask, r.key, r.val)) atomicAdd(status, 1u);
+    }
+}
+__global__ __launch_bounds__(256) void uniq_lookup_rows_kernel(const uint64_t* __restrict__ rows, uint64_t n, const UniqSlot* __restrict__ t, uint64_t mask,
+                                                               uint64_t* answers)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = rows[2 * i];
+        uint64_t r = UNIQ_EMPTY;
+        if (h == UNIQ_EMPTY) {
+            r = t[mask + 1].val;
+        } else {
+            uint64_t s = uniq_slot(h, mask), probes = 0;
+            for (;;) {
+                const UniqSlot cur = uniq_peek(t + s);
+                if (cur.key == h) { r = cur.val; break; }
+                if (cur.key == UNIQ_EMPTY || ++probes > mask) break;
+                s = (s + 1) & mask;
+            }
+        }
+        answers[i] = r;
+    }
+}
+// first_seen[i] = answers[slot[i]] (the answers arrive in row order)
+__global__ __launch_bounds__(256) void uniq_gather_kernel(const uint64_t* __restrict__ answers, const uint32_t* __restrict__ slot, uint64_t n, uint64_t base,
+                                                          uint64_t* first_seen, uint8_t* keep)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t r = answers[slot[i]];
+        first_seen[i] = r;
+        if (keep) keep[i] = r == base + i;
+    }
+}
+
 // every slot = {EMPTY, EMPTY}: 16 bytes per thread and trip; also zeroes the overflow counter
 __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t slots, uint32_t* overflow)
 {
@@ -1462,6 +1560,59 @@ int circkit_uniq_lookup_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t 
     CK_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(uniq_lookup_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_first_seen,
                        (uint8_t*)nullptr, (uint64_t)0);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+// ---- the multi-GPU exchange's device steps (circkit_amd/uniq.py; include/circkit.h)
+int circkit_uniq_partition_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t n, uint64_t base_index, uint32_t world, uint64_t* d_rows,
+                                  uint64_t* d_counts, uint32_t* d_slot)
+{
+    if (!c || !d_counts || world == 0 || world > UNIQ_MAX_WORLD || (n && (!d_hash || !d_rows || !d_slot))) return CIRCKIT_ERR_INVALID_ARG;
+    if (n >= 0xFFFFFFFFull) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_partition_device: n must be < 2^32 - 1");
+    CK_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c, 0, UNIQ_MAX_WORLD);             // d_hash: the scatter's cursors (64 x u64)
+    if (rc) return rc;
+    CK_HIP(c, hipMemsetAsync(d_counts, 0, world * sizeof(uint64_t), c->stream));
+    CK_HIP(c, hipMemsetAsync(c->d_hash, 0, UNIQ_MAX_WORLD * sizeof(uint64_t), c->stream));
+    if (n == 0) return CIRCKIT_OK;
+    hipLaunchKernelGGL(uniq_partition_count_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, world, (unsigned long long*)d_counts);
+    hipLaunchKernelGGL(uniq_partition_scatter_kernel, dim3(N_CU * 4), dim3(256), 0, c->stream, d_hash, n, base_index, world,
+                       (const unsigned long long*)d_counts, (unsigned long long*)c->d_hash, d_rows, d_slot);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_insert_rows_device(circkit_ctx* c, const uint64_t* d_rows, uint64_t n)
+{
+    if (!c || (n && !d_rows)) return CIRCKIT_ERR_INVALID_ARG;
+    if (!c->d_table || c->uniq_local) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called (since the last circkit_uniq_resolve_device)");
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(uniq_insert_rows_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_rows, n, c->d_table, c->uniq_mask, c->d_counters + 4);
+    CK_HIP(c, hipGetLastError());
+    c->uniq_count += n;
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_lookup_rows_device(circkit_ctx* c, const uint64_t* d_rows, uint64_t n, uint64_t* d_answers)
+{
+    if (!c || (n && (!d_rows || !d_answers))) return CIRCKIT_ERR_INVALID_ARG;
+    if (!c->d_table || c->uniq_local) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called (since the last circkit_uniq_resolve_device)");
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(uniq_lookup_rows_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_rows, n, (const UniqSlot*)c->d_table, c->uniq_mask, d_answers);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+int circkit_uniq_gather_device(circkit_ctx* c, const uint64_t* d_answers, const uint32_t* d_slot, uint64_t n, uint64_t base_index, uint64_t* d_first_seen,
+                               uint8_t* d_keep)
+{
+    if (!c || (n && (!d_answers || !d_slot || !d_first_seen))) return CIRCKIT_ERR_INVALID_ARG;
+    if (n == 0) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(uniq_gather_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_answers, d_slot, n, base_index, d_first_seen, d_keep);
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
 }

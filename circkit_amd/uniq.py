@@ -13,7 +13,9 @@ collective on the canonicalize path), then ONE exchange step resolves the duplic
 * exchange="partition" (default): the key space is cut into `world` hash ranges, one per rank.  Every rank sends
   each (hash, global index) pair to the owner of its range (all-to-all), the owner folds what it receives into its
   table -- 1/world of all keys -- and answers every pair with the smallest index it has seen for that hash (a
-  second all-to-all, same shape backwards).  Per GPU and 10M-record shard at world 8: 140 MB out + 140 MB in +
+  second all-to-all, same shape backwards).  With the device table every step between the collectives is a kernel
+  of the library (circkit_uniq_partition_device / _insert_rows_ / _lookup_rows_ / _gather_device); the torch-op
+  version below it serves the CPU tests' stand-in tables.  Per GPU and 10M-record shard at world 8: 140 MB out + 140 MB in +
   70 MB of answers each way, one table insert and one lookup of 10M keys.
 * exchange="allgather": every rank gathers all hash arrays (world x 80 MB in) and folds ALL keys into its own table
   (world x the insert work).  Kept for comparison and as the simpler reference of the two.
@@ -66,6 +68,35 @@ class DeviceTable:
         self.ctx.uniq_resolve_device(hashes, hashes.numel(), base_index, fs, keep)
         return fs, keep
 
+    # the exchange's device steps (kernels of the library instead of argsort / bincount / gather ops)
+    def partition(self, hashes, base_index, world):
+        """(rows [n, 2] = (hash, global index) grouped by owner rank, counts [world], slot [n])"""
+        self._bind()
+        n = hashes.numel()
+        rows = torch.empty((n, 2), dtype=torch.int64, device=hashes.device)
+        counts = torch.empty(world, dtype=torch.int64, device=hashes.device)
+        slot = torch.empty(n, dtype=torch.int32, device=hashes.device)
+        self.ctx.uniq_partition_device(hashes, n, base_index, world, rows, counts, slot)
+        return rows, counts, slot
+
+    def insert_rows(self, rows):
+        self._bind()
+        self.ctx.uniq_insert_rows_device(rows, rows.shape[0])
+
+    def lookup_rows(self, rows):
+        self._bind()
+        out = torch.empty(rows.shape[0], dtype=torch.int64, device=rows.device)
+        self.ctx.uniq_lookup_rows_device(rows, rows.shape[0], out)
+        return out
+
+    def gather(self, answers, slot, base_index):
+        self._bind()
+        n = slot.numel()
+        fs = torch.empty(n, dtype=torch.int64, device=slot.device)
+        keep = torch.empty(n, dtype=torch.bool, device=slot.device)
+        self.ctx.uniq_gather_device(answers, slot, n, base_index, fs, keep)
+        return fs, keep
+
     def check(self):
         """Waits for the queued table work; raises if the table overflowed."""
         self.ctx.uniq_status()
@@ -86,6 +117,21 @@ def first_seen(table, hashes, base_index=0, group=None, exchange="partition", fo
     world = dist.get_world_size(group) if initialised else 1
     if world == 1 and not (force_exchange and initialised) and hasattr(table, "resolve"):
         return table.resolve(hashes, base_index)
+    if exchange == "partition" and hasattr(table, "partition") and world <= 64 and (world > 1 or (force_exchange and initialised)):
+        # the device table: every step between the collectives is a kernel of the library
+        rows, send_counts, slot = table.partition(hashes, base_index, world)
+        recv_counts = torch.empty_like(send_counts)
+        dist.all_to_all_single(recv_counts, send_counts, group=group)
+        in_split, out_split = send_counts.tolist(), recv_counts.tolist()
+        recv = torch.empty((sum(out_split), 2), dtype=torch.int64, device=hashes.device)
+        dist.all_to_all_single(recv, rows, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        table.reset(max(recv.shape[0], 1))
+        if recv.shape[0]:
+            table.insert_rows(recv)
+        answers = table.lookup_rows(recv)
+        back = torch.empty(n, dtype=torch.int64, device=hashes.device)
+        dist.all_to_all_single(back, answers, output_split_sizes=in_split, input_split_sizes=out_split, group=group)
+        return table.gather(back, slot, base_index)
     idx = torch.arange(base_index, base_index + n, dtype=torch.int64, device=hashes.device)
     if world == 1 and not (force_exchange and initialised):
         table.reset(n)

@@ -144,6 +144,20 @@ int circkit_uniq_insert_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_
  * partition, circkit_amd/uniq.py) are a subset of every other rank's shard, not a contiguous range */
 int circkit_uniq_insert_pairs_device(circkit_ctx* ctx, const uint64_t* d_hash, const uint64_t* d_index, uint64_t n);
 int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t* d_first_seen);
+/* The device steps of the multi-GPU exchange (circkit_amd/uniq.py, exchange = "partition"; the reference is one process:
+ * src/uniq.rs:27 has no counterpart).  The key space is cut into `world` (<= 64) ranges, a key belongs to rank
+ * ((hash >> 20) & 0x7FFFFFFF) % world.
+ *   partition    d_rows[n][2] = {hash, base_index + i} with the rows of one owner together, owners in rank order (what
+ *                an all-to-all sends), d_counts[world] = rows per owner, d_slot[i] = row of record i.  n < 2^32 - 1.
+ *   insert_rows  folds received rows into the table;  lookup_rows  d_answers[k] = smallest index seen for row k's hash
+ *   gather       d_first_seen[i] = d_answers[d_slot[i]] (the answers come back in row order), d_keep[i] (nullable) =
+ *                1 iff that is base_index + i */
+int circkit_uniq_partition_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t base_index, uint32_t world,
+                                  uint64_t* d_rows, uint64_t* d_counts, uint32_t* d_slot);
+int circkit_uniq_insert_rows_device(circkit_ctx* ctx, const uint64_t* d_rows, uint64_t n);
+int circkit_uniq_lookup_rows_device(circkit_ctx* ctx, const uint64_t* d_rows, uint64_t n, uint64_t* d_answers);
+int circkit_uniq_gather_device(circkit_ctx* ctx, const uint64_t* d_answers, const uint32_t* d_slot, uint64_t n, uint64_t base_index,
+                               uint64_t* d_first_seen, uint8_t* d_keep);
 /* One shard in one call: reset (sized for n keys), insert with indices base_index .. base_index + n - 1, lookup, and
  * d_keep[i] (nullable, uint8) = 1 iff d_first_seen[i] == base_index + i -- the reference's per-record decision "emit,
  * or write a table row" (src/uniq.rs:47-62).  n < 2^32 - 1.  The table's contents are private to the call (it keeps

@@ -648,6 +648,42 @@ def test_uniq_resolve_device_answers_and_keeps_its_table_private(ctx, O):
     ctx.use_own_stream()
 
 
+@pytest.mark.parametrize("world", [1, 3, 8, 64])
+def test_uniq_exchange_kernels(ctx, O, world):
+    """The device steps of the multi-GPU exchange, without the collectives: circkit_uniq_partition_device groups the
+    (hash, global index) rows by owner rank -- the same owner as circkit_amd/uniq.py's _owner --, counts them and tells every
+    record its row; rows folded and answered in row order (insert_rows / lookup_rows) and gathered back through the
+    slots give the oracle's first-seen."""
+    import torch
+    from circkit_amd import uniq
+    rng = np.random.default_rng(14 + world)
+    n, base = 500_000, 7_000_000_000
+    h = rng.integers(0, 100_000, size=n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+    h[rng.integers(0, n, 30)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_h = torch.from_numpy(h.astype(np.int64)).to(dev)
+    table = uniq.DeviceTable(ctx)
+    rows, counts, slot = table.partition(d_h, base, world)
+    torch.cuda.synchronize()
+    owner = uniq._owner(d_h, world)
+    assert torch.equal(counts, torch.bincount(owner, minlength=world))
+    r = rows.cpu().numpy(); sl = slot.cpu().numpy().astype(np.int64)
+    assert len(np.unique(sl)) == n                                          # every record its own row
+    assert np.array_equal(r[sl, 0].astype(np.uint64), h) and np.array_equal(r[sl, 1], base + np.arange(n))
+    row_owner = uniq._owner(rows[:, 0].contiguous(), world).cpu().numpy()
+    assert np.all(np.diff(row_owner) >= 0)                                  # owners in rank order
+    table.reset(n)
+    table.insert_rows(rows)
+    answers = table.lookup_rows(rows)
+    fs, keep = table.gather(answers, slot, base)
+    table.check()
+    exp = O.uniq_first_seen(h)
+    assert np.array_equal(fs.cpu().numpy().astype(np.uint64), exp + np.uint64(base))
+    assert np.array_equal(keep.cpu().numpy(), exp == np.arange(n, dtype=np.uint64))
+    ctx.use_own_stream()
+
+
 def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
     """The ROWS == 2 build of the streaming kernel (records up to 2032 bases, two packed words per lane): chosen from the
     batch's lengths -- by the host for host buffers, on the device for device buffers (both builds are launched, the
