@@ -31,7 +31,8 @@ def pmc_traffic(workload):
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         for entry in t.get("entries", [t]):
             if entry.get("workload") == workload:
-                return entry["traffic_bytes"], "profiles/traffic.json (%s)" % entry.get("source", "rocprofv3 --pmc, separate passes")
+                return entry["traffic_bytes"], "profiles/traffic.json (%s; %s)" % (entry.get("source", "rocprofv3 --pmc, separate passes"),
+                                                                                   entry.get("scope", "per launch"))
     except (OSError, ValueError, KeyError):
         pass
     return None, None
