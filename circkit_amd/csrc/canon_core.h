@@ -589,6 +589,23 @@ CK_DEV uint32_t fast_pack_n(u32x4 v, uint32_t& nmask16, uint32_t& miss)
     nmask16 = (((m[0] << 4 | m[1]) << 4 | m[2]) << 4) | m[3];
     return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
 }
+// the same with the mask in the strand's own layout (0b11 at every N, first symbol in the top bits): the register routine
+// moves it through the shuffles and funnels its strand words take
+CK_DEV uint32_t fast_pack_n2(u32x4 v, uint32_t& nmask, uint32_t& miss)
+{
+    const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+    uint32_t u[4], m[4];
+    miss = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t sel = (d[k] >> 1) & HASH_MASK;                       // A0 C1 T2 G3 ... N7
+        miss = sad_u8(perm(0x4E000000u, CHK2_LO, sel), d[k], miss);
+        u[k] = udot4(perm(0x02000000u, 0x02030100u, sel), 0x01041040u, 0u);
+        m[k] = udot4((sel >> 2) & 0x01010101u, 0x030C30C0u, 0u);
+    }
+    nmask = (((m[0] << 8 | m[1]) << 8 | m[2]) << 8) | m[3];
+    return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
+}
 // 16-entry LDS table: 4 mask bits (bit 3 = first symbol) -> 0x01 in the byte of every N (times 'G' ^ 'N' or 'C' ^ 'N')
 CK_DEV void fast_lutn_init(uint32_t* lutn, uint32_t tid, uint32_t nthreads)
 {

@@ -254,10 +254,16 @@ CK_DEV void fast_shape(FastShape& sh, uint32_t n)
 // K16: two-level scan (8-symbol prefixes first).  The staged streaming kernel is bound by vector-instruction issue and
 // gains from it; the latency-bound rescue pass lost a third of its speed to it (mixed lengths: 225 -> 330 us) and keeps
 // the one-level scan.
-template <bool HASH, bool AUX, bool GH = false, bool K16 = false>
+// NM (bytes-only builds): the record may hold N.  F has them packed as G -- the reverse strand then shows C --, Nm marks
+// them (0b11 per N, the strand's layout).  Either way a key with an N is BELOW its true value and every other key exact
+// (C < G < N), so the winner stands if the symbols that decided -- 8 at level 1, 16 at level 2 -- hold no N; else false,
+// and the caller's 4-bit routine has the record.  `bad` = lanes with a byte outside ACGTN.  (canon_core.h
+// canon_record_mode2n is the same idea in the LDS tiers.)
+template <bool HASH, bool AUX, bool GH = false, bool K16 = false, bool NM = false>
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
-                       uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr)
+                       uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr, uint32_t Nm = 0)
 {
+    static_assert(!NM || (!HASH && !AUX), "the N-mask variant writes bytes only");
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
     if (sh.n != n) fast_shape(sh, n);
@@ -267,6 +273,12 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         const uint32_t ext = lshr64(A, B, 32 - ((16 - r) & 15) * 2);
         const uint32_t fix = bfi(~(0xFFFFFFFFu >> (2 * r)), F, B >> (2 * r));
         F = t >= nwv ? ext : (t == nwf ? fix : F);        // r == 0: nwf == nwv, `fix` is never selected
+        if constexpr (NM) {
+            const uint32_t An = shfl(Nm, sh.ext_lane), Bn = shfl(Nm, sh.ext_lane + 1);
+            const uint32_t extn = lshr64(An, Bn, 32 - ((16 - r) & 15) * 2);
+            const uint32_t fixn = bfi(~(0xFFFFFFFFu >> (2 * r)), Nm, Bn >> (2 * r));
+            Nm = t >= nwv ? extn : (t == nwf ? fixn : Nm);
+        }
     }
     const bool fwd_only = AUX && (a.flags & CK_FLAG_FWD_ONLY) != 0;
     // reverse-complement strand from the extended forward words:
@@ -285,8 +297,9 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
     // minimal prefixes differ and the winner's is owned by one position -- the minimal keys ARE the first symbols of the
     // two minimal rotations (lib/src/canonicalize.rs:58-62: forward only if strictly smaller).
     bool fwd = true, tie = true, uE = false, uF = true;
-    uint32_t idx = 0, iF = 0;
+    uint32_t idx = 0, iF = 0, decided = 16;                // symbols of the winner's key that decided (NM)
     if constexpr (K16) {
+        decided = 8;
         uint32_t mF = valid ? word_min_key16(F, Fn) : 0xFFFFu, mC = valid ? word_min_key16(C, Cn) : 0xFFFFu;
         uint32_t MF, MC;
         wave_min2_u32(mF, mC, MF, MC);
@@ -301,6 +314,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         // rotation index is asked for, which for the reverse strand is counted from the forward strand's minimal
         // rotation.  Equal keys on both strands (reverse-complement palindromes), or a minimal key that is still not
         // unique: left to the general kernel.
+        decided = 16;
         uint32_t mF = valid ? word_min_key<2>(F, Fn) : ~0u, mC = valid ? word_min_key<2>(C, Cn) : ~0u;
         uint32_t MF, MC;
         wave_min2_u32(mF, mC, MF, MC);
@@ -313,12 +327,29 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         if (tie || !uE || !uF) return false;
     }
     const uint32_t E = fwd ? F : C;
+    uint32_t Em = Nm;
+    if constexpr (NM) {
+        if (!fwd) Em = bitrev(lshr64(shfl(Nm, sh.rc_lane), shfl(Nm, sh.rc_lane + 1), sh.rc_sh));      // the mask in the reverse strand's order
+        if ((reg_sym_word(Em, idx, n) >> (32 - 2 * decided)) != 0) return false;                       // an N among the symbols that decided
+    }
     {
         const uint32_t o = sh.out_o;
         const bool hash = HASH && a.out_hash != nullptr && n > 240;     // XXH3's long-input path; shorter: xxh3 pass
         const bool store = a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL));
         if (store || hash) {
-            const u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
+            u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
+            if constexpr (NM) {
+                const uint32_t m = reg_sym_word(Em, idx + o, n);
+                if (m) {
+                    // the decoded 'G' (forward) or 'C' (reverse) of every marked symbol becomes 'N': bit 2j of a reversed
+                    // mask byte -> 0x01 in byte j by one multiplication (1 + 2^6 + 2^12 + 2^18), times the XOR constant
+                    const uint32_t rm = bitrev(m), fix = fwd ? 0x09u : 0x0Du;
+                    cell.x ^= (((rm & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                    cell.y ^= ((((rm >> 8) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                    cell.z ^= ((((rm >> 16) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                    cell.w ^= ((((rm >> 24) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                }
+            }
             if (store && valid) store16(a.out_bytes + off + o, cell);
             if (hash) {
                 if constexpr (GH) {

@@ -161,7 +161,20 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
                 const uint64_t bad = ballot(miss != 0) & (~0ull >> (64 - nch));         // 3 <= nch <= 64
-                if (ALPHA && bad != 0) {
+                if constexpr (ALPHA && !HASH && !AUX) {
+                    // N is the usual stranger: 2-bit words with N as G plus a mask, the register routine's N-mask variant
+                    // (255 -> ~200 VALU per record against the 4-bit routine below, and 16-symbol keys instead of 8: hardly
+                    // a tie); what it refuses -- an N among the deciding symbols, a gap -- the 4-bit routine takes
+                    if (bad != 0) {
+                        uint32_t nm, miss2;
+                        const uint32_t Pn = fast_pack_n2(v, nm, miss2);
+                        const uint64_t badn = ballot(miss2 != 0) & (~0ull >> (64 - nch));
+                        if (badn == 0)
+                            done = fast_canon<false, false, false, true, true>(a, lut, hc, shape, rec, off, n, lshr64(Pn, wave_shl1(Pn), 32 - 2 * a16), 0, nullptr,
+                                                                               lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
+                    }
+                }
+                if (ALPHA && bad != 0 && !done) {
                     // {-,A,C,G,N,T} at 4 bits per symbol: 64 bits per lane, the record's offset in its first chunk
                     // removed by a 128-bit funnel with the next lane's pair (4 * a16 bits)
                     uint32_t H, L, bad4;
@@ -171,7 +184,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                     const uint64_t W = a16 ? (X << (4 * a16)) | (Xn >> (64 - 4 * a16)) : X;
                     done = fast_canonw<4, HASH, false>(a, lut, hc, rec, off, n, (uint32_t)(W >> 32), (uint32_t)W, b4 != 0);
                     tried4 = true;
-                } else {
+                } else if (!done) {
                     done = fast_canon<HASH, AUX, GH, true>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
                 }
             }

@@ -462,3 +462,38 @@ def test_team_mode_with_n_bitmask():
         assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, len(s))
         kept_with_n_in_window += b"N" in want[i][0][:16]
     assert done >= len(seqs) // 2 and kept_with_n_in_window >= 3, (done, len(seqs), kept_with_n_in_window)
+
+
+@pytest.mark.parametrize("staged", [1, 3])
+def test_register_routine_with_n_mask(staged):
+    """The streaming kernel's ALPHA build, bytes only: records of 48..1008 bases with a few N go through fast_canon's N-mask
+    variant (N packed as G, the reverse strand shows C, a mask word beside the strand word) -- every length class of the
+    periodic extension, both strands, N next to the minimal window; planted A-runs with an N / G / T / C behind them put
+    the N among the deciding symbols (the routine must refuse and the 4-bit routine answer)."""
+    rng = np.random.default_rng(1700 + staged)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    seqs = []
+    for L in list(range(48, 81)) + list(range(990, 1009)) + [127, 128, 129, 255, 256, 257, 511, 512, 513]:
+        s = bytearray(seqsets.random_mixed(1701 + L, 1, L, L)[0])
+        for p in rng.integers(0, L, size=max(1, L // 100)):
+            s[int(p)] = ord("N")
+        seqs.append(bytes(s))
+    for case in range(150):
+        L = int(rng.integers(200, 1009))
+        bg = bytearray(rng.choice(list(b"CGT"), size=L, p=[0.2, 0.4, 0.4]).astype(np.uint8).tobytes())
+        run = int(rng.integers(2, 15))
+        for sp in sorted(rng.choice(np.arange(10, L - 30, 25), size=int(rng.integers(1, 4)), replace=False)):
+            motif = b"A" * run + bytes(rng.choice(list(b"NGTCN"), size=1).astype(np.uint8)) + bytes(rng.choice(list(b"ACGTN"), size=5, p=[.23, .23, .23, .23, .08]).astype(np.uint8))
+            if rng.random() < 0.5:
+                motif = motif.translate(comp)[::-1]
+            bg[sp:sp + len(motif)] = motif
+        seqs.append(bytes(bg))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=False, staged=staged, slice_dw=4096, n_waves=12,
+                                                               alpha=True)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i][0], (i, len(s), s[:60])
+    assert emu.last_fast_count >= len(seqs) - 70        # the planted near-ties and the batch's last group take the passes behind
