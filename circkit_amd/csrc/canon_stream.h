@@ -155,37 +155,43 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 // lane t packs the aligned chunk c0 + t of the image; the record starts a16 bytes into chunk c0, so
                 // the byte funnel is done on the packed words: 2*a16 bits, with the next lane's word behind
                 const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;
-                uint32_t miss;
                 const u32x4 v = lds_load16(img + 4 * ((rel >> 4) + t));
-                const uint32_t P = fast_pack(v, miss);
+                const uint64_t chunks = ~0ull >> (64 - nch);                            // 3 <= nch <= 64
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
-                const uint64_t bad = ballot(miss != 0) & (~0ull >> (64 - nch));         // 3 <= nch <= 64
+                uint64_t bad;                       // lanes with a byte the 2-bit routines cannot take
                 if constexpr (ALPHA && !HASH && !AUX) {
-                    // N is the usual stranger: 2-bit words with N as G plus a mask, the register routine's N-mask variant
-                    // (255 -> ~200 VALU per record against the 4-bit routine below, and 16-symbol keys instead of 8: hardly
-                    // a tie); what it refuses -- an N among the deciding symbols, a gap -- the 4-bit routine takes
-                    if (bad != 0) {
-                        uint32_t nm, miss2;
-                        const uint32_t Pn = fast_pack_n2(v, nm, miss2);
-                        const uint64_t badn = ballot(miss2 != 0) & (~0ull >> (64 - nch));
-                        if (badn == 0)
-                            done = fast_canon<false, false, false, true, true>(a, lut, hc, shape, rec, off, n, lshr64(Pn, wave_shl1(Pn), 32 - 2 * a16), 0, nullptr,
-                                                                               lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
+                    // N is the usual stranger: ONE packing pass gives the 2-bit words with N as G plus the mask, and the
+                    // register routine's N-mask variant takes the record (220 VALU per record against 255 with the 4-bit
+                    // routine below, and 16-symbol keys instead of 8: hardly a tie).  A batch of this build holds an N in
+                    // most records; the few without take the plain routine.  What the variant refuses -- an N among the
+                    // deciding symbols -- and records with a gap go to the 4-bit routine.
+                    uint32_t nm, miss2;
+                    const uint32_t Pn = fast_pack_n2(v, nm, miss2);
+                    bad = ballot(miss2 != 0) & chunks;
+                    const uint64_t with_n = ballot(nm != 0) & chunks;
+                    if (bad == 0) {
+                        const uint32_t Fw = lshr64(Pn, wave_shl1(Pn), 32 - 2 * a16);
+                        if (with_n == 0) done = fast_canon<false, false, false, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr);
+                        else done = fast_canon<false, false, false, true, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr, lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
                     }
+                    bad |= with_n;                  // (what the 4-bit routine is for)
+                } else {
+                    uint32_t miss;
+                    const uint32_t P = fast_pack(v, miss);
+                    bad = ballot(miss != 0) & chunks;
+                    if (!ALPHA || bad == 0) done = fast_canon<HASH, AUX, GH, true>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
                 }
                 if (ALPHA && bad != 0 && !done) {
                     // {-,A,C,G,N,T} at 4 bits per symbol: 64 bits per lane, the record's offset in its first chunk
                     // removed by a 128-bit funnel with the next lane's pair (4 * a16 bits)
                     uint32_t H, L, bad4;
                     fast_pack4(v, H, L, bad4);
-                    const uint64_t b4 = ballot(bad4 != 0) & (~0ull >> (64 - nch));
+                    const uint64_t b4 = ballot(bad4 != 0) & chunks;
                     const uint64_t X = ((uint64_t)H << 32) | L, Xn = ((uint64_t)wave_shl1(H) << 32) | wave_shl1(L);
                     const uint64_t W = a16 ? (X << (4 * a16)) | (Xn >> (64 - 4 * a16)) : X;
                     done = fast_canonw<4, HASH, false>(a, lut, hc, rec, off, n, (uint32_t)(W >> 32), (uint32_t)W, b4 != 0);
                     tried4 = true;
-                } else if (!done) {
-                    done = fast_canon<HASH, AUX, GH, true>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
                 }
             }
             // The entry's flag: the 4-bit register routine has had this record (a tied 8-symbol key, mostly) -- the rescue
