@@ -80,3 +80,19 @@ def test_integration_md_binds_every_declared_symbol():
     block = text[text.index("## 2. Declarations"):text.index("## 3. Drop-in")]
     bound = sorted(set(re.findall(r"pub fn (circkit_[a-z0-9_]+)\s*\(", block)))
     assert bound == header_symbols()
+
+
+def test_bench_and_smoke_fail_loudly_without_a_gpu():
+    """No CPU fallback anywhere on the measured path: without a HIP device bench.py stops with a message (it never times
+    the oracle in the product's place) and the ctx refuses to exist."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no HIP device" in (r.stderr + r.stdout)
+    import circkit_amd
+    with pytest.raises(circkit_amd.CirckitError):
+        circkit_amd.Context(0)
