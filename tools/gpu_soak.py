@@ -51,4 +51,6 @@ soak("uniform 1009..2032", lambda n, g: torch.randint(1009, 2033, (n,), generato
 soak("95% short + 5% long", lambda n, g: torch.where(torch.rand(n, generator=g) < 0.95, torch.randint(300, 901, (n,), generator=g),
                                                      torch.randint(3000, 8001, (n,), generator=g)), 2_000_000, 45)
 soak("log-uniform 200..20000", lambda n, g: torch.exp(np.log(200.0) + torch.rand(n, generator=g, dtype=torch.float64) * np.log(100.0)).to(torch.int64), 500_000, 46)
+soak("log-uniform 200..300000", lambda n, g: torch.exp(np.log(200.0) + torch.rand(n, generator=g, dtype=torch.float64) * np.log(1500.0)).to(torch.int64), 40_000, 47)
+soak("fixed 120000 (small batch)", lambda n, g: torch.full((n,), 120_000), 550, 48)
 print("soak ok")
