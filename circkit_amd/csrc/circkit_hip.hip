@@ -810,13 +810,13 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #define CK_TIER_A 1280
 #endif
 #ifndef CK_TIER_B1
-#define CK_TIER_B1 1900     // 2-bit records up to ~30 kb, with a few N (strand + bitmask) up to ~20.2 kb
+#define CK_TIER_B1 1900     // (one-wave slice sizes of single-record calls: launch_single)
 #endif
 #ifndef CK_TIER_B2
 #define CK_TIER_B2 3324
 #endif
 constexpr int N_TIERS = 5;
-constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40188u : 31996u };     // + 260 dwords of counter and decode table per workgroup
+constexpr uint32_t TIER_DW[N_TIERS] = { CK_TIER_A, CK_TIER_B1, CK_TIER_B2, 9980, CK_LUT_STRIDE == 1 ? 40188u : 31996u };     // + TIER_EXTRA_DW per workgroup
 constexpr uint32_t TIER_EXTRA_DW = 4 + ck::FAST_LUT_DW + ck::FAST_LUTN_DW;        // counter, decode table, N patch table
 constexpr uint32_t TIER_D_DW = TIER_DW[N_TIERS - 1];
 // A batch's LDS stages: A (four waves x 5 KiB), C (four waves x 9.7 KiB) and the team stage (sixteen waves, the whole LDS).
@@ -842,7 +842,8 @@ struct circkit_ctx {
     std::string err;
     uint8_t* d_comp = nullptr;
     uint32_t* d_counters = nullptr;      // [3] unprocessed records; [4] uniq table overflow
-    // segmented deferral lists: streaming kernel -> tier A -> tier B -> tier C (one segment per producing workgroup)
+    // segmented deferral lists: streaming kernel -> rescue pass / mixed kernel -> stage A -> stage C -> team stage -> global
+    // stage (one segment per producing workgroup)
     uint32_t* d_lists[N_TIERS + 1] = {}; // [0] streaming kernel -> rescue pass, [i + 1] input list of tier i (output of the stage before)
     uint32_t* d_seg_counts = nullptr;    // [(N_TIERS + 1) * seg_alloc]
     uint64_t list_cap = 0, seg_alloc = 0;
@@ -929,7 +930,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     // launch geometry: G virtual workgroups for the streaming kernel, the rescue pass and tier A (segment b of a list
-    // belongs to workgroup b); the one-wave tiers C, D take several segments per workgroup each
+    // belongs to workgroup b); stage C and the team stage take several segments per workgroup each
     const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
     const uint64_t per_step = aux ? StreamCAux::GROUP : StreamC::GROUP;    // records a workgroup takes per iteration
     const uint64_t blocks = (n + per_step - 1) / per_step;
