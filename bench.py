@@ -11,10 +11,16 @@ hash-range all-to-all of circkit_amd/uniq.py over RCCL, inside the timed step.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts its own ranks: the parent -- which
+never imports torch and never touches a GPU -- runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on this
+very file as a child process, lets rank 0's JSON line through on stdout and exits with the launcher's code.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,6 +42,20 @@ def pmc_traffic(workload):
     except (OSError, ValueError, KeyError):
         pass
     return None, None
+
+
+def self_launch(n_ranks):
+    """One process per GPU, started from here: the launcher is a CHILD (never exec: this process may already hold state the
+    box forbids replacing), stdout / stderr are inherited so rank 0's JSON line is this command's output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -62,6 +82,11 @@ def main():
                     help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
                          "strand duplicates, hash + first-seen); mixed = configs[3] (1M records, L ~ 1/L on [200, 20000])")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    force_dist = os.environ.get("CIRCKIT_BENCH_FORCE_DIST") == "1"   # rehearse the launcher + RCCL path on one GPU
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
+        sys.exit(self_launch(args.gpus))           # before anything of torch / HIP is loaded in this process
 
     import numpy as np
     import torch
@@ -77,7 +102,6 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    force_dist = os.environ.get("CIRCKIT_BENCH_FORCE_DIST") == "1"   # rehearse the RCCL path on one GPU
     use_dist = world > 1 or force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -96,3 +96,20 @@ def test_bench_and_smoke_fail_loudly_without_a_gpu():
     import circkit_amd
     with pytest.raises(circkit_amd.CirckitError):
         circkit_amd.Context(0)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher around it (as the driver runs it) spawns N ranks through
+    torch.distributed.run; on this GPU-less box they get as far as the device check -- the failure is the children's
+    "no HIP device", not a WORLD_SIZE complaint of the parent."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--records", "1000", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    text = r.stderr + r.stdout
+    assert r.returncode != 0 and "no HIP device" in text and "WORLD_SIZE=" not in text, text[-2000:]

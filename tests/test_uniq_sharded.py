@@ -36,6 +36,43 @@ class OracleTable:
         return torch.tensor([best[x] for x in hashes.numpy().astype(np.uint64).tolist()], dtype=torch.int64)
 
 
+class RowsTable(OracleTable):
+    """NumPy stand-in for the DEVICE table's exchange steps, to the contract of include/circkit.h (partition / insert_rows /
+    lookup_rows / gather): with it uniq.first_seen takes the branch a multi-GPU job takes (circkit_amd/uniq.py, "the device
+    table: every step between the collectives is a kernel of the library"), so split sizes, row order across peers and the
+    slot gather run under a real peer.  Inside an owner's group the rows are deliberately NOT in record order (the kernel
+    promises none): an exchange that relied on it would fail here."""
+
+    def partition(self, hashes, base_index, world):
+        from circkit_amd import uniq
+        self.partitioned = True
+        n = hashes.numel()
+        h = hashes.view(torch.int64)
+        owner = uniq._owner(h, world).numpy()
+        rng = np.random.default_rng(base_index + 17)
+        order = np.lexsort((rng.permutation(n), owner))              # owners in rank order, any order inside
+        rows = torch.empty((n, 2), dtype=torch.int64)
+        rows[:, 0] = h[torch.from_numpy(order)]
+        rows[:, 1] = torch.from_numpy(order.astype(np.int64)) + base_index
+        counts = torch.from_numpy(np.bincount(owner, minlength=world).astype(np.int64))
+        slot = torch.empty(n, dtype=torch.int32)
+        slot[torch.from_numpy(order)] = torch.arange(n, dtype=torch.int32)
+        return rows, counts, slot
+
+    def insert_rows(self, rows):
+        self.insert_pairs(rows[:, 0].contiguous(), rows[:, 1].contiguous())
+
+    def lookup_rows(self, rows):
+        if rows.shape[0] == 0:
+            return torch.empty(0, dtype=torch.int64)
+        return self.lookup(rows[:, 0].contiguous())
+
+    def gather(self, answers, slot, base_index):
+        self.gathered = True
+        fs = answers[slot.long()]
+        return fs, fs == torch.arange(base_index, base_index + slot.numel(), dtype=torch.int64)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -44,32 +81,38 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, hashes, cuts, q, exchange):
+def _worker(rank, world, port, hashes, cuts, q, exchange, rows_table=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from circkit_amd import uniq
     lo, hi = cuts[rank], cuts[rank + 1]
-    fs, keep = uniq.first_seen(OracleTable(), torch.from_numpy(hashes[lo:hi].astype(np.int64)), base_index=lo, exchange=exchange)
+    table = RowsTable() if rows_table else OracleTable()
+    fs, keep = uniq.first_seen(table, torch.from_numpy(hashes[lo:hi].astype(np.int64)), base_index=lo, exchange=exchange)
+    if rows_table:
+        assert table.partitioned and table.gathered            # the device-rows branch really ran
     q.put((rank, fs.numpy(), keep.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,world", [("partition", 2), ("allgather", 2), ("partition", 3)])
-def test_sharded_first_seen_matches_single_process(exchange, world):
+@pytest.mark.parametrize("exchange,world,rows_table", [("partition", 2, False), ("allgather", 2, False), ("partition", 3, False),
+                                                       ("partition", 2, True), ("partition", 3, True), ("partition", 4, True)])
+def test_sharded_first_seen_matches_single_process(exchange, world, rows_table):
     """Both exchange steps of circkit_amd/uniq.py -- the hash-range all-to-all (default) and the all-gather -- give
-    the single-process first-seen result, with unequal shards (one of them empty at world 3) and sign-bit hashes."""
+    the single-process first-seen result, with unequal shards (one of them empty at world 3 and 4) and sign-bit hashes.
+    rows_table: the branch the device table takes (partition -> all_to_all -> insert_rows / lookup_rows -> all_to_all ->
+    gather), with the table's kernels replaced by RowsTable."""
     from oracle import oracle as O
     rng = np.random.default_rng(3)
     n = 5000
     hashes = rng.integers(0, 1200, size=n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)   # ~4x duplicates, top bit set in half
-    cuts = [0, 1777, n] if world == 2 else [0, 1777, 1777, n]                                  # unequal shards
+    cuts = {2: [0, 1777, n], 3: [0, 1777, 1777, n], 4: [0, 5, 1777, 1777, n]}[world]          # unequal shards
     expect = O.uniq_first_seen(hashes).astype(np.int64)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, hashes, cuts, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, hashes, cuts, q, exchange, rows_table)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict()
