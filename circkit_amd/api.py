@@ -14,7 +14,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcirckit_hip.so")
+# CIRCKIT_LIB: another build of the same library (tools/build_variant.sh: A/B timing, the poison-check build of tests/) --
+# selected here instead of being copied over the in-tree file, which build.py's mtime check would then take for current
+LIB_PATH = os.environ.get("CIRCKIT_LIB") or os.path.join(_HERE, "libcirckit_hip.so")
 
 OK = 0
 ERRORS = {-1: "INVALID_ARG", -2: "NO_DEVICE", -3: "HIP", -4: "TOO_LONG", -5: "OOM", -6: "NOT_ASCII"}
@@ -219,6 +221,14 @@ class Context:
 
     def uniq_resolve_device(self, d_hash, n, base_index, d_first_seen, d_keep=None):
         self._check(self._lib.circkit_uniq_resolve_device(self._h, _ptr(d_hash), int(n), int(base_index), _ptr(d_first_seen), _ptr(d_keep)))
+
+    def uniq_first_seen(self, hashes, base_index=0):
+        """Host-buffer streaming form (the CLI's batch loop): folds the batch into the ctx table, grown on demand, and
+        returns first_seen (numpy uint64)."""
+        hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.empty(max(len(hashes), 1), dtype=np.uint64)
+        self._check(self._lib.circkit_uniq_first_seen(self._h, _ptr(hashes), len(hashes), int(base_index), _ptr(out)))
+        return out[:len(hashes)]
 
     def uniq_status(self):
         """Waits for the queued table work; raises CirckitError (OOM) if keys found no slot."""

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void uniq_lookup_kernel(const uint64_t* __rest
 }
 
 // circkit_uniq_resolve_device's own pair of kernels: one shard, one insert pass, one lookup pass, LOCAL indices
-// (i < 2^31).  The value word is split: its high half receives the index of the record that CLAIMED the key -- a plain
+// (i < 2^32 - 1: 0xFFFFFFFF is the "nothing yet" value of either half).  The value word is split: its high half receives the index of the record that CLAIMED the key -- a plain
 // store, the claimer needs no second atomic --, its low half the smallest index among the records that found the key
 // present (32-bit atomicMin, skipped when the peek already shows a smaller index in either half).  first-seen =
 // min(low, high).  With threads taking records roughly in index order a key costs ONE atomic (the CAS) instead of two:
@@ -838,6 +838,7 @@ struct circkit_ctx {
     int device = -1;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_order = nullptr;       // circkit_ctx_set_stream: the new stream waits for what the ctx queued on the old one
     bool timed = false;
     std::string err;
     uint8_t* d_comp = nullptr;
@@ -864,6 +865,7 @@ struct circkit_ctx {
     UniqSlot* d_table = nullptr;         // [uniq_mask + 2]
     uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
     bool uniq_local = false;                  // the table holds circkit_uniq_resolve_device's split local values
+    bool uniq_lost = false;                   // a rehash failed half-way: the stream's earlier batches are gone -- every uniq call fails until circkit_uniq_reset
 };
 
 namespace {
@@ -1257,6 +1259,7 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     c->stream = c->own_stream;
     CK_HIP(c, hipEventCreate(&c->ev0));
     CK_HIP(c, hipEventCreate(&c->ev1));
+    CK_HIP(c, hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
     CK_HIP(c, hipHostMalloc((void**)&c->h_mode, 64, hipHostMallocMapped));
     c->h_mode[0] = 0; c->h_mode[1] = 0;
     CK_HIP(c, hipHostGetDevicePointer((void**)&c->d_mode, (void*)c->h_mode, 0));
@@ -1287,6 +1290,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     for (uint32_t* p : c->d_lists) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->h_mode) (void)hipHostFree((void*)c->h_mode);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -1295,18 +1299,30 @@ int circkit_ctx_destroy(circkit_ctx* c)
 
 const char* circkit_last_error(const circkit_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
+// The ctx's lists, counters, hash flags and table are shared by everything it enqueues, and a caller may hand a later call
+// tensors an earlier one has just written: work on the new stream must not overtake what is still queued on the old one.
+// An event on the old stream, waited for by the new one -- no host-side wait; switching to the stream already bound costs
+// nothing (circkit_amd/uniq.py rebinds before every table call).
+static int switch_stream(circkit_ctx* c, hipStream_t s)
+{
+    if (s == c->stream) return CIRCKIT_OK;
+    CK_HIP(c, hipSetDevice(c->device));
+    CK_HIP(c, hipEventRecord(c->ev_order, c->stream));
+    CK_HIP(c, hipStreamWaitEvent(s, c->ev_order, 0));
+    c->stream = s;
+    return CIRCKIT_OK;
+}
+
 int circkit_ctx_set_stream(circkit_ctx* c, void* s)
 {
     if (!c) return CIRCKIT_ERR_INVALID_ARG;
-    c->stream = (hipStream_t)s;      // NULL is a real stream: HIP's default (null) stream
-    return CIRCKIT_OK;
+    return switch_stream(c, (hipStream_t)s);      // NULL is a real stream: HIP's default (null) stream
 }
 
 int circkit_ctx_use_own_stream(circkit_ctx* c)
 {
     if (!c) return CIRCKIT_ERR_INVALID_ARG;
-    c->stream = c->own_stream;
-    return CIRCKIT_OK;
+    return switch_stream(c, c->own_stream);
 }
 
 int circkit_ctx_synchronize(circkit_ctx* c)
@@ -1483,6 +1499,7 @@ int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
     CK_HIP(c, hipGetLastError());
     c->uniq_count = 0;
     c->uniq_local = false;
+    c->uniq_lost = false;
     return CIRCKIT_OK;
 }
 
@@ -1493,6 +1510,9 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
     if (!c || (n && (!hash || !first_seen))) return CIRCKIT_ERR_INVALID_ARG;
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
+    if (c->uniq_lost)
+        return fail(c, CIRCKIT_ERR_HIP, "the uniq table was lost in a failed rehash: the earlier batches of this stream are gone "
+                    "(circkit_uniq_reset starts a new one)");
     if (c->uniq_local) { const int rc0 = circkit_uniq_reset(c, n); if (rc0) return rc0; }      // a resolve result is not a stream's table
     if (!c->d_table || (c->uniq_count + n) * 2 > c->uniq_mask + 1) {
         uint64_t cap = 1 << 16;
@@ -1502,9 +1522,16 @@ int circkit_uniq_first_seen(circkit_ctx* c, const uint64_t* hash, uint64_t n, ui
         hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, nt, cap + 1, (uint32_t*)nullptr);
         if (c->d_table) {
             hipLaunchKernelGGL(uniq_rehash_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, (const UniqSlot*)c->d_table, c->uniq_mask + 2, nt, cap - 1);
-            const hipError_t e = hipStreamSynchronize(c->stream);
+            hipError_t e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess && getenv("CIRCKIT_TEST_FAIL_REHASH")) e = hipErrorUnknown;      // fault injection (tests/test_gpu_parity.py)
             (void)hipFree(c->d_table); c->d_table = nullptr;
-            if (e != hipSuccess) { (void)hipFree(nt); return fail(c, CIRCKIT_ERR_HIP, "uniq table rehash failed: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) {
+                // the old table is gone and the new one holds who knows what: not a state to go on from silently -- every
+                // later call fails until the caller starts over with circkit_uniq_reset
+                (void)hipFree(nt);
+                c->uniq_mask = 0; c->uniq_count = 0; c->uniq_lost = true;
+                return fail(c, CIRCKIT_ERR_HIP, "uniq table rehash failed: %s", hipGetErrorString(e));
+            }
         } else {
             CK_HIP(c, hipMemsetAsync(c->d_counters + 4, 0, 4, c->stream));
         }
@@ -1571,6 +1598,7 @@ int circkit_uniq_partition_device(circkit_ctx* c, const uint64_t* d_hash, uint64
 {
     if (!c || !d_counts || world == 0 || world > UNIQ_MAX_WORLD || (n && (!d_hash || !d_rows || !d_slot))) return CIRCKIT_ERR_INVALID_ARG;
     if (n >= 0xFFFFFFFFull) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_partition_device: n must be < 2^32 - 1");
+    if ((uintptr_t)d_rows & 15) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_rows must be 16-byte aligned");
     CK_HIP(c, hipSetDevice(c->device));
     int rc = ensure_staging(c, 0, UNIQ_MAX_WORLD);             // d_hash: the scatter's cursors (64 x u64)
     if (rc) return rc;
@@ -1587,6 +1615,7 @@ int circkit_uniq_partition_device(circkit_ctx* c, const uint64_t* d_hash, uint64
 int circkit_uniq_insert_rows_device(circkit_ctx* c, const uint64_t* d_rows, uint64_t n)
 {
     if (!c || (n && !d_rows)) return CIRCKIT_ERR_INVALID_ARG;
+    if ((uintptr_t)d_rows & 15) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_rows must be 16-byte aligned");
     if (!c->d_table || c->uniq_local) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called (since the last circkit_uniq_resolve_device)");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
@@ -1599,6 +1628,7 @@ int circkit_uniq_insert_rows_device(circkit_ctx* c, const uint64_t* d_rows, uint
 int circkit_uniq_lookup_rows_device(circkit_ctx* c, const uint64_t* d_rows, uint64_t n, uint64_t* d_answers)
 {
     if (!c || (n && (!d_rows || !d_answers))) return CIRCKIT_ERR_INVALID_ARG;
+    if ((uintptr_t)d_rows & 15) return fail(c, CIRCKIT_ERR_INVALID_ARG, "d_rows must be 16-byte aligned");
     if (!c->d_table || c->uniq_local) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_reset has not been called (since the last circkit_uniq_resolve_device)");
     if (n == 0) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
@@ -1623,9 +1653,9 @@ int circkit_uniq_gather_device(circkit_ctx* c, const uint64_t* d_answers, const 
 int circkit_uniq_resolve_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t n, uint64_t base_index, uint64_t* d_first_seen, uint8_t* d_keep)
 {
     if (!c || (n && (!d_hash || !d_first_seen))) return CIRCKIT_ERR_INVALID_ARG;
+    if (n >= 0xFFFFFFFFull) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_resolve_device: n must be < 2^32 - 1");     // before the table is touched
     int rc = circkit_uniq_reset(c, n);
     if (rc || n == 0) return rc;
-    if (n >= 0xFFFFFFFFull) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_resolve_device: n must be < 2^32 - 1");
     hipLaunchKernelGGL(uniq_resolve_insert_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, c->d_table, c->uniq_mask, c->d_counters + 4);
     hipLaunchKernelGGL(uniq_resolve_lookup_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask,
                        d_first_seen, d_keep, base_index);

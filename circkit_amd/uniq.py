@@ -33,7 +33,10 @@ class DeviceTable:
     Stream ordering: the table kernels read tensors that torch ops and RCCL collectives have just produced, so they
     must run on the stream those are ordered on.  Every call therefore (re)binds the ctx to torch's CURRENT stream
     of the ctx's device -- a blocking collective (`async_op=False`) makes that stream wait for RCCL's -- instead of
-    the ctx's private non-blocking stream, which is ordered after nothing."""
+    the ctx's private non-blocking stream.  The rebind is a lasting side effect on the ctx; circkit_ctx_set_stream
+    orders the stream it moves to behind everything the ctx queued on the one it leaves (an event, no host wait), so
+    `ctx.canonicalize_batch_device(..., out_xxh3=h)` on the old stream followed by `first_seen(DeviceTable(ctx), h)` reads
+    a finished `h`.  Binding the stream that is already bound costs nothing."""
 
     def __init__(self, ctx):
         self.ctx = ctx

@@ -48,7 +48,11 @@ int circkit_ctx_create(int device, circkit_ctx** out);
 int circkit_ctx_destroy(circkit_ctx* ctx);
 const char* circkit_last_error(const circkit_ctx* ctx);
 /* Launch all subsequent work of this ctx on `hip_stream` (a hipStream_t; NULL = HIP's default stream).
- * A fresh ctx launches on a private non-blocking stream; circkit_ctx_use_own_stream returns to it. */
+ * A fresh ctx launches on a private non-blocking stream; circkit_ctx_use_own_stream returns to it.
+ * Switching ORDERS the streams: the new stream waits (on the device, through an event -- the host does not block) for
+ * everything the ctx has queued on the stream it leaves, so un-synchronised batches on either side of a switch cannot
+ * overlap in the ctx's lists, counters and table, and a call after the switch may read what a call before it wrote.
+ * The stream being left must still exist.  Binding the stream that is already bound is free. */
 int circkit_ctx_set_stream(circkit_ctx* ctx, void* hip_stream);
 int circkit_ctx_use_own_stream(circkit_ctx* ctx);
 /* Block until all work queued by this ctx has finished. */
@@ -148,7 +152,9 @@ int circkit_uniq_lookup_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_
  * src/uniq.rs:27 has no counterpart).  The key space is cut into `world` (<= 64) ranges, a key belongs to rank
  * ((hash >> 20) & 0x7FFFFFFF) % world.
  *   partition    d_rows[n][2] = {hash, base_index + i} with the rows of one owner together, owners in rank order (what
- *                an all-to-all sends), d_counts[world] = rows per owner, d_slot[i] = row of record i.  n < 2^32 - 1.
+ *                an all-to-all sends; any order inside an owner's group), d_counts[world] = rows per owner, d_slot[i] =
+ *                row of record i.  n < 2^32 - 1.  d_rows -- here and in insert_rows / lookup_rows -- must be 16-byte
+ *                aligned (a row is one 16-byte access).
  *   insert_rows  folds received rows into the table;  lookup_rows  d_answers[k] = smallest index seen for row k's hash
  *   gather       d_first_seen[i] = d_answers[d_slot[i]] (the answers come back in row order), d_keep[i] (nullable) =
  *                1 iff that is base_index + i */
@@ -171,7 +177,8 @@ int circkit_uniq_status(circkit_ctx* ctx, uint32_t* n_overflowed);
 
 /* Host-buffer form for streaming hosts (the CLI's batch loop): folds this batch's hashes (global indices
  * base_index .. base_index + n - 1) into the ctx table -- created and grown on demand, earlier batches kept --
- * and returns first_seen[i] for the batch.  Synchronizes. */
+ * and returns first_seen[i] for the batch.  Synchronizes.  If growing the table fails half-way (a failed rehash), the
+ * earlier batches are lost: this call and every later one return CIRCKIT_ERR_HIP until circkit_uniq_reset. */
 int circkit_uniq_first_seen(circkit_ctx* ctx, const uint64_t* hash, uint64_t n, uint64_t base_index,
                             uint64_t* first_seen);
 

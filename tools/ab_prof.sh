@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for v in "$@"; do
-  cp circkit_amd/libcirckit_hip_$v.so circkit_amd/libcirckit_hip.so
+  export CIRCKIT_LIB=$(pwd)/circkit_amd/libcirckit_hip_$v.so     # read by circkit_amd/api.py; the in-tree library stays as built
   tools/prof_run.sh abprof_$v ${AB_ARGS} > /dev/null 2>&1
   echo "== $v"
   python - <<PY

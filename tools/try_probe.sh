@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 script=$1; shift
 for v in "$@"; do
-  cp circkit_amd/libcirckit_hip_$v.so circkit_amd/libcirckit_hip.so
+  export CIRCKIT_LIB=$(pwd)/circkit_amd/libcirckit_hip_$v.so     # read by circkit_amd/api.py; the in-tree library stays as built
   echo "== $v"; timeout -k 10 200 python $script 2>&1 | grep -v amdgpu.ids
 done
