@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="records timed on the host cores (rank 0, N=1); default: 100k records per usable core (~0.7 s)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-buffer leg (end_to_end)")
+    ap.add_argument("--no-copy", action="store_true", help="skip the same-box plain-copy yardstick (roofline.copy_ceiling_gbps)")
     ap.add_argument("--exchange", default="partition", choices=["partition", "allgather"], help="uniq at --gpus > 1")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (each with its own ctx and output buffers) the steps are dealt to round-robin, so that the "
@@ -210,34 +212,56 @@ def main():
 
     if rank == 0:
         seq_per_s = world * N * args.steps / dt
-        algo_bytes = 2 * total + 8 * N                 # read L + write L per record + one u64 offset
+        # read L + write L per record + one u64 offset; uniq: + the u64 hash per record.  The table's scattered
+        # accesses (a 16-byte slot read + written by the insert, read by the lookup: 32 B per record) are NOT in SURVEY's
+        # formula; the fraction with them is reported next to the judged one.
+        algo_bytes = 2 * total + 8 * N
+        table_bytes = 0
         if args.workload == "uniq":
-            algo_bytes += 8 * N + 32 * N               # + u64 hash per record + table insert/lookup (key + value each)
+            algo_bytes += 8 * N
+            table_bytes = 32 * N
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         nvar = ", %g %% of the bases replaced by N" % (100 * args.n_frac) if args.n_frac > 0 else ""
+        # the kernel chain the step really ran: which streaming build the batch's own mode picked, which table path
+        stream_build = "canon_stream_kernel<StreamCfg<16,2,1,%d>,%s,false,false,%s>" % (
+            2 if 1008 < L <= 2032 else 1, "true" if args.workload == "uniq" else "false", "true" if nvar and L <= 1008 else "false")
         if args.workload == "canonicalize":
             metric = "canonicalize sequences/sec (%s x %d b synthetic FASTA payload)" % (
                 "10M" if N == 10_000_000 else "100M over 8 GPUs" if config5 else "%d per GPU" % N, L)
             wl = "canonicalize, %d records x %d b per GPU%s, uniform ACGT seed 42%s, device-resident CSR (%s)" % (
                 N, L, ", 100M records in total" if config5 else "", nvar,
                 "BASELINE configs[4]" if config5 else "BASELINE configs[1]" if (N, L) == (10_000_000, 1000) and not nvar else "variant of BASELINE configs[1]")
-            kernel = "canon_stream_kernel<StreamCfg<16,2,1,1>,false,false>" if not nvar else "canon_stream_kernel + canon_rescue_kernel"
+            kernel = stream_build if not nvar else stream_build + " (+ canon_rescue_kernel<false,false,true> and canon_kernel<4> for its leftovers)"
             par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
         elif args.workload == "uniq":
             metric = "uniq sequences/sec (%d x %d b per GPU, ~50%% rotational/strand duplicates)" % (N, L)
             wl = ("uniq --canonicalize, %d records x %d b per GPU, half are rotated / reverse-complemented copies, shuffled "
                   "(BASELINE configs[2])" % (N, L))
-            kernel = "canon_stream_kernel<StreamCfg<16,2,1,1>,true,false> + uniq_insert_kernel + uniq_lookup_kernel"
+            if not use_dist:
+                kernel = stream_build + " + uniq_resolve_insert_kernel + uniq_resolve_lookup_kernel"
+            elif args.exchange == "partition":
+                kernel = stream_build + " + uniq_partition_kernel + all_to_all x3 + uniq_insert_rows_kernel + uniq_lookup_rows_kernel + uniq_gather_kernel"
+            else:
+                kernel = stream_build + " + all_gather + uniq_insert_kernel x%d + uniq_lookup_kernel" % world
             par = ("records sharded over %d GPU(s); first-seen resolved by one hash-range all-to-all over RCCL (exchange=%s)"
                    % (world, args.exchange)) if use_dist else "1 GPU: the ctx hash table, no collective"
         else:
             metric = "canonicalize sequences/sec (%d records, 200b-%dkb log-uniform lengths)" % (N, args.max_len // 1000)
             wl = "canonicalize, %d records, lengths log-uniform on [200, %d], %d bases per GPU%s (%s)" % (
                 N, args.max_len, total, nvar, "BASELINE configs[3]" if (N, args.max_len) == (1_000_000, 20000) and not nvar else "variant of BASELINE configs[3]")
-            kernel = ("canon_mixed_kernel (whole step; per-kernel split in profiles/)" if not nvar else
-                      "canon_rescue_kernel + canon_kernel tiers (whole step; per-kernel split in profiles/)")
+            kernel = ("canon_mixed_kernel<%s> (whole step; per-kernel split in profiles/)" % ("true" if nvar else "false"))
             par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
         traffic, traffic_source = pmc_traffic("%s %d x %d" % (args.workload, N, L) + (" n%g" % args.n_frac if nvar else ""))
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes}
+        if table_bytes:
+            roofline["frac_incl_table_accesses"] = (algo_bytes + table_bytes) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            roofline["table_access_bytes"] = table_bytes
+        if not args.no_copy:
+            roofline.update(copy_ceiling(torch, ctx, stream, d_bytes, d_out, total, achieved))
+            step()                                      # d_out holds the canonical records again (the checks below read it)
+            torch.cuda.synchronize()
         result = {
             "metric": metric, "value": seq_per_s, "unit": "sequences/s",
             "gbases_per_s": world * total * args.steps / dt / 1e9,
@@ -248,12 +272,13 @@ def main():
             "config": {"workload": wl, "records_per_gpu": N, "records_total": world * N,
                        "record_len": L if args.workload != "mixed" else "200..%d (mean %d)" % (args.max_len, total // N),
                        "parallelism": par + ("; steps dealt round-robin to %d HIP streams (one ctx each)" % S if S > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+            "roofline": roofline,
+            "unprocessed_records": "0 (circkit_ctx_batch_status after the last step of every lane; all steps run the same batch)",
         }
         if unique_global is not None:
             result["unique_records"] = unique_global
+        if world == 1 and not args.no_e2e:
+            result["end_to_end"] = end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out)
         if world == 1 and not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state)
             if not result["cpu_baseline"]["gpu_output_matches"]:
@@ -264,6 +289,74 @@ def main():
         dist.destroy_process_group()
     for ln in lanes:
         ln["ctx"].close()
+
+
+def copy_ceiling(torch, ctx, stream, d_src, d_dst, total, achieved):
+    """What THIS box copies, in this process, right behind the timed steps: the batch's payload (`total` bytes in, `total`
+    out) through the library's plain copy kernels (circkit_bench_copy_device: four shapes + hipMemcpyAsync), best of them,
+    HIP events on the launch stream.  Boxes of the pool differ by several percent; `frac_of_copy` is the figure that does not."""
+    nb = total & ~15
+    best, best_v, per_variant = None, None, {}
+    for v in range(5):
+        ctx.bench_copy_device(d_src, d_dst, nb, v)                     # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(3):
+            ctx.bench_copy_device(d_src, d_dst, nb, v)
+        e1.record(stream)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        per_variant[str(v)] = 2 * nb / (ms * 1e-3) / 1e9
+        if best is None or ms < best:
+            best, best_v = ms, v
+    gbps = 2 * nb / (best * 1e-3) / 1e9
+    return {"copy_ceiling_gbps": gbps, "frac_of_copy": achieved / gbps, "copy_ms": best,
+            "copy_note": "same process, same box: %d B read + %d B written by a plain 16 B/lane copy kernel (best of 5 shapes: variant %d); "
+                         "GB/s per variant: %s" % (nb, nb, best_v, json.dumps({k: round(x) for k, x in per_variant.items()}))}
+
+
+def end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out):
+    """PCIe-inclusive rate (never `value`): the HOST-buffer entry point circkit_canonicalize_batch on page-locked
+    buffers -- H2D of payload + offsets, the same kernels, D2H of the canonical bytes, one synchronisation -- on a sample
+    of the batch (<= 1M records, <= 1 GB).  One call after the other, nothing overlapped: what one thread of a host
+    program sees per call (the CLI overlaps parse, copies and kernels: DESIGN.md)."""
+    import ctypes
+    lib = circkit_amd.load_library()
+    S = min(N, 1_000_000)
+    if args.workload == "mixed":
+        S = min(S, 250_000)
+    h_off_t = d_off[:S + 1].cpu()
+    h_off = (h_off_t - h_off_t[0]).numpy().astype(np.uint64)
+    nb = int(h_off[-1])
+    first = int(h_off_t[0])
+    pin_in, pin_out = lib.circkit_host_alloc(nb + 64), lib.circkit_host_alloc(nb + 64)
+    if not pin_in or not pin_out:
+        return {"error": "circkit_host_alloc failed"}
+    h_in = torch.frombuffer((ctypes.c_uint8 * nb).from_address(pin_in), dtype=torch.uint8)
+    h_in.copy_(d_bytes[first:first + nb])
+    torch.cuda.synchronize()
+    want_hash = args.workload == "uniq"
+    h_hash = np.empty(S, dtype=np.uint64) if want_hash else None
+
+    def call():
+        rc = lib.circkit_canonicalize_batch(ctx._h, pin_in, h_off.ctypes.data, S, pin_out, None, None,
+                                            h_hash.ctypes.data if want_hash else None)
+        if rc:
+            raise SystemExit("circkit_canonicalize_batch failed: %d" % rc)
+    call()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    dt = (time.perf_counter() - t0) / reps
+    got = torch.frombuffer((ctypes.c_uint8 * nb).from_address(pin_out), dtype=torch.uint8)
+    same = bool(torch.equal(got, d_out[first:first + nb].cpu()))
+    lib.circkit_host_free(pin_in)
+    lib.circkit_host_free(pin_out)
+    return {"value": S / dt, "unit": "sequences/s", "kind": "PCIe-inclusive, host-buffer API (circkit_canonicalize_batch), pinned buffers, no overlap between calls",
+            "sample": "first %d records (%d bases) of the batch" % (S, nb), "ms_per_call": dt * 1e3,
+            "h2d_plus_d2h_gbps": 2 * nb / dt / 1e9, "pcie_ceiling_note": "PCIe Gen5 x16 ~63 GB/s per direction: <= 6.3e7 sequences/s at 1 kb if nothing overlaps less",
+            "matches_device_path": same}
 
 
 def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
@@ -304,6 +397,13 @@ def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
     if want_hash:
         O.uniq_first_seen(hh)
     one_core = S1 / (time.perf_counter() - c1)
+    # the reference AS WRITTEN indexes with chars().nth(): O(n^2) per record.  Cost model (oracle/circkit_oracle.c
+    # ck_oracle_lmsr_index_nth) on a small subsample, all cores; same answers, checked
+    SQ = min(S, max(64, int(10_000 * (1000.0 / L) ** 2)) if args.workload != "mixed" else 400)
+    c2 = time.perf_counter()
+    q_out = O.canonicalize_batch_nth(h_in[:int(h_off[SQ])], h_off[:SQ + 1], threads=cores)
+    qdt = time.perf_counter() - c2
+    q_same = bool(np.array_equal(q_out, h_out[:int(h_off[SQ])]))
     what = {"canonicalize": "normalize-free canonicalize", "uniq": "canonicalize + XXH3-64 on all cores, then the first-seen map on one "
             "thread (the reference's main-thread closure)", "mixed": "canonicalize"}[args.workload]
     return {
@@ -313,6 +413,11 @@ def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
                   "(linear-time byte-indexed Duval variant, faster than the reference's O(n^2) chars().nth() loop), %d pthreads = every core "
                   "this process may use (%d visible, cgroup quota %d); one_core_value on the first %d records" % (S, nb, what, cores, visible, quota, S1),
         "gpu_output_matches": same,
+        "reference_faithful_quadratic": {
+            "value": SQ / qdt, "unit": "sequences/s", "cores": cores, "sample": "first %d records" % SQ, "same_answers": q_same,
+            "note": "COST MODEL, not the reference binary: the restatement with the reference's own access pattern -- "
+                    "s.chars().nth(i) walks the text from its start at every access (lib/src/canonicalize.rs:17-27), O(n^2) per "
+                    "record; how fast the real walk is depends on the rustc that built the binary"},
     }
 
 

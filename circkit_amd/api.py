@@ -64,6 +64,7 @@ SIGNATURES = {
     "circkit_fasta_free": (None, [_vp]),
     "circkit_synth_fill_device": (_i, [_vp, _u64, _u64, _u64, _vp]),
     "circkit_fixed_offsets_device": (_i, [_vp, _u64, _u64, _u64, _vp]),
+    "circkit_bench_copy_device": (_i, [_vp, _vp, _vp, _u64, _u32]),
     "circkit_normalize": (_sz, [_vp, _sz, _vp, ctypes.POINTER(_i)]),
     "circkit_version": (ctypes.c_char_p, []),
 }
@@ -192,6 +193,9 @@ class Context:
     def fixed_offsets_device(self, base, record_len, n_records, d_offsets):
         self._check(self._lib.circkit_fixed_offsets_device(self._h, int(base), int(record_len), int(n_records),
                                                            _ptr(d_offsets)))
+
+    def bench_copy_device(self, d_src, d_dst, nbytes, variant=0):
+        self._check(self._lib.circkit_bench_copy_device(self._h, _ptr(d_src), _ptr(d_dst), int(nbytes), int(variant)))
 
     def uniq_reset(self, expected_keys):
         self._check(self._lib.circkit_uniq_reset(self._h, int(expected_keys)))

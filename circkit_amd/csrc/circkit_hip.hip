@@ -528,6 +528,24 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(uint64_t seed, uint64_t
     }
 }
 
+// Plain device-to-device copy, 16 bytes per lane, UNROLL loads in flight per lane: the same-process, same-box yardstick the
+// bench line quotes next to the canonicalize kernel's rate (circkit_bench_copy_device; shapes from tools/microbench/ceiling_bench.hip).
+typedef uint32_t copy_v4 __attribute__((ext_vector_type(4)));
+template <int UNROLL>
+__global__ __launch_bounds__(256) void bench_copy_kernel(const copy_v4* __restrict__ in, copy_v4* __restrict__ out, uint64_t n16)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * UNROLL;
+    uint64_t i = (uint64_t)blockIdx.x * 256 * UNROLL + threadIdx.x;
+    for (; i + 256 * (UNROLL - 1) < n16; i += stride) {
+        copy_v4 r[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) r[u] = in[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) out[i + u * 256] = r[u];
+    }
+    for (; i < n16; i += 256) out[i] = in[i];                 // the last, partial tile of the workgroup that owns it
+}
+
 __global__ void fixed_offsets_kernel(uint64_t base, uint64_t len, uint64_t n, uint64_t* off)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -1694,6 +1712,25 @@ int circkit_fixed_offsets_device(circkit_ctx* c, uint64_t base, uint64_t len, ui
     if (!c || !d_offsets) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(fixed_offsets_kernel, dim3(N_CU * 4), dim3(256), 0, c->stream, base, len, n, d_offsets);
+    CK_HIP(c, hipGetLastError());
+    return CIRCKIT_OK;
+}
+
+// Measurement helper: enqueues one plain copy of `bytes` bytes (rounded down to 16) on the ctx stream.
+int circkit_bench_copy_device(circkit_ctx* c, const void* d_src, void* d_dst, uint64_t bytes, uint32_t variant)
+{
+    if (!c || !d_src || !d_dst || variant >= 5) return CIRCKIT_ERR_INVALID_ARG;
+    if (((uintptr_t)d_src | (uintptr_t)d_dst) & 15) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_bench_copy_device: 16-byte aligned buffers");
+    CK_HIP(c, hipSetDevice(c->device));
+    const uint64_t n16 = bytes / 16;
+    const copy_v4* in = (const copy_v4*)d_src; copy_v4* out = (copy_v4*)d_dst;
+    switch (variant) {
+    case 0: hipLaunchKernelGGL(bench_copy_kernel<4>, dim3(2048), dim3(256), 0, c->stream, in, out, n16); break;
+    case 1: hipLaunchKernelGGL(bench_copy_kernel<8>, dim3(2048), dim3(256), 0, c->stream, in, out, n16); break;
+    case 2: hipLaunchKernelGGL(bench_copy_kernel<4>, dim3(8192), dim3(256), 0, c->stream, in, out, n16); break;
+    case 3: hipLaunchKernelGGL(bench_copy_kernel<2>, dim3(65536), dim3(256), 0, c->stream, in, out, n16); break;
+    default: CK_HIP(c, hipMemcpyAsync(d_dst, d_src, n16 * 16, hipMemcpyDeviceToDevice, c->stream)); break;      // the runtime's own copy
+    }
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
 }

@@ -209,6 +209,13 @@ int circkit_synth_fill_device(circkit_ctx* ctx, uint64_t seed, uint64_t first_ba
 int circkit_fixed_offsets_device(circkit_ctx* ctx, uint64_t base, uint64_t record_len, uint64_t n_records,
                                  uint64_t* d_offsets);
 
+/* Measurement helper, no counterpart in the reference (the roofline is quoted against what this very box
+ * copies): enqueues ONE plain device-to-device copy of `bytes` bytes (rounded down to a multiple of 16; both buffers
+ * 16-byte aligned) on the ctx stream.  variant 0..3 = copy kernels of different shapes (16 B per lane; 4 / 8 / 4 / 2 loads
+ * in flight per lane over 2048 / 2048 / 8192 / 65536 workgroups), 4 = hipMemcpyAsync.  bench.py times each and reports the
+ * best as roofline.copy_ceiling_gbps. */
+int circkit_bench_copy_device(circkit_ctx* ctx, const void* d_src, void* d_dst, uint64_t bytes, uint32_t variant);
+
 /* ---- host-side normalisation used by the packer ------------------------------------------------ */
 /* needletail::sequence::normalize(seq, false)      call sites src/canonicalize.rs:24, src/uniq.rs:35
  * Host logic of the CSR packer (strips line breaks while it computes offsets); returns the new length,

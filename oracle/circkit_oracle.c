@@ -51,6 +51,46 @@ size_t ck_oracle_lmsr_index(const uint8_t *s, size_t len)
     return (size_t)res;                               /* :35 */
 }
 
+/* ------------------------------------------------------------------------------------------
+ * COST MODEL of the reference as written (bench.py: cpu_baseline.reference_faithful_quadratic).
+ * lib/src/canonicalize.rs:17-27 index the &str with `s.chars().nth(i)`: Chars::nth walks the UTF-8 text from its
+ * start, one char boundary at a time -- O(i) per access, three accesses per step of the inner loop (:18/:20, :22, :25),
+ * hence O(n^2) per record where the byte-indexed transcription above is linear.  Same answers (ASCII: every byte is a
+ * char); only the time differs.  How fast the real binary's walk is depends on the rustc that built it (newer std
+ * count boundaries a word at a time), so this is a model of the SHAPE of the cost, not a stand-in for the binary.
+ * ---------------------------------------------------------------------------------------- */
+static uint8_t chars_nth(const uint8_t *s, size_t len, size_t k)
+{
+    size_t seen = 0;
+    for (size_t i = 0; i < len; ++i) {
+        if ((s[i] & 0xC0) != 0x80) {                  /* not a continuation byte: a char starts here */
+            if (seen == k) return s[i];
+            ++seen;
+        }
+    }
+    return 0;                                         /* (the reference would panic on the unwrap) */
+}
+
+size_t ck_oracle_lmsr_index_nth(const uint8_t *s, size_t len)
+{
+    int64_t n = (int64_t)len;
+    int64_t res = 0, l = 0;
+    while (l < n) {
+        res = l;
+        int64_t r = l, p = l + 1;
+        while (r < n) {
+            uint8_t c = (p < n) ? chars_nth(s, len, (size_t)p) : chars_nth(s, len, (size_t)(p - n));   /* :17-21 */
+            if (chars_nth(s, len, (size_t)r) > c) break;                                               /* :22 */
+            if (chars_nth(s, len, (size_t)r) < c) r = l - 1;                                           /* :25 */
+            r += 1;
+            p += 1;
+        }
+        int64_t a = r, b = l + p - r;
+        l = a > b ? a : b;
+    }
+    return (size_t)res;
+}
+
 /* The naive oracle of the reference's own proptest (lib/src/canonicalize.rs:154-164):
  * smallest i whose rotation is lexicographically minimal (strict `<`, :159). */
 size_t ck_oracle_lmsr_index_simple(const uint8_t *s, size_t n)
@@ -112,6 +152,20 @@ void ck_oracle_canonicalize(const uint8_t *s, size_t n, uint8_t *out)
     ck_oracle_lmsr(rc, n, b);                /* :56 */
     if (memcmp(a, b, n) < 0) memcpy(out, a, n);   /* :58-59 */
     else memcpy(out, b, n);                       /* :60-61 */
+    free(a); free(rc); free(b);
+}
+
+/* canonicalize with the quadratic lmsr_index above (cost model) */
+static void canonicalize_nth(const uint8_t *s, size_t n, uint8_t *out)
+{
+    if (n == 0) return;
+    uint8_t *a = (uint8_t *)malloc(n), *rc = (uint8_t *)malloc(n), *b = (uint8_t *)malloc(n);
+    size_t i = ck_oracle_lmsr_index_nth(s, n);
+    memcpy(a, s + i, n - i); memcpy(a + (n - i), s, i);
+    ck_oracle_revcomp(a, n, rc);
+    i = ck_oracle_lmsr_index_nth(rc, n);
+    memcpy(b, rc + i, n - i); memcpy(b + (n - i), rc, i);
+    memcpy(out, memcmp(a, b, n) < 0 ? a : b, n);
     free(a); free(rc); free(b);
 }
 
@@ -266,6 +320,7 @@ uint64_t ck_oracle_xxh3_64(const uint8_t *in, size_t len)
 typedef struct {
     const uint8_t *bytes; const uint64_t *off; uint8_t *out; uint64_t *hash;
     uint64_t lo, hi;
+    int nth;                                          /* the quadratic cost model instead of the linear transcription */
 } job_t;
 
 static void *batch_worker(void *arg)
@@ -273,7 +328,9 @@ static void *batch_worker(void *arg)
     job_t *j = (job_t *)arg;
     for (uint64_t i = j->lo; i < j->hi; ++i) {
         uint64_t o = j->off[i], n = j->off[i + 1] - o;
-        if (j->out) {
+        if (j->nth) {
+            canonicalize_nth(j->bytes + o, n, j->out + o);
+        } else if (j->out) {
             ck_oracle_canonicalize(j->bytes + o, n, j->out + o);
             if (j->hash) j->hash[i] = ck_oracle_xxh3_64(j->out + o, n);
         } else if (j->hash) {
@@ -286,8 +343,21 @@ static void *batch_worker(void *arg)
     return NULL;
 }
 
+static void canonicalize_batch(const uint8_t *bytes, const uint64_t *offsets, uint64_t n_records,
+                               uint8_t *out_bytes, uint64_t *out_xxh3, int threads, int nth);
 void ck_oracle_canonicalize_batch(const uint8_t *bytes, const uint64_t *offsets, uint64_t n_records,
                                   uint8_t *out_bytes, uint64_t *out_xxh3, int threads)
+{
+    canonicalize_batch(bytes, offsets, n_records, out_bytes, out_xxh3, threads, 0);
+}
+/* the same batch through the quadratic cost model (out_bytes required) */
+void ck_oracle_canonicalize_batch_nth(const uint8_t *bytes, const uint64_t *offsets, uint64_t n_records,
+                                      uint8_t *out_bytes, int threads)
+{
+    canonicalize_batch(bytes, offsets, n_records, out_bytes, NULL, threads, 1);
+}
+static void canonicalize_batch(const uint8_t *bytes, const uint64_t *offsets, uint64_t n_records,
+                               uint8_t *out_bytes, uint64_t *out_xxh3, int threads, int nth)
 {
     comp_init();
     if (threads < 1) threads = 1;
@@ -295,7 +365,7 @@ void ck_oracle_canonicalize_batch(const uint8_t *bytes, const uint64_t *offsets,
     pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * threads);
     job_t *jobs = (job_t *)malloc(sizeof(job_t) * threads);
     for (int t = 0; t < threads; ++t) {
-        jobs[t].bytes = bytes; jobs[t].off = offsets; jobs[t].out = out_bytes; jobs[t].hash = out_xxh3;
+        jobs[t].bytes = bytes; jobs[t].off = offsets; jobs[t].out = out_bytes; jobs[t].hash = out_xxh3; jobs[t].nth = nth;
         jobs[t].lo = n_records * t / threads; jobs[t].hi = n_records * (t + 1) / threads;
         if (threads == 1) batch_worker(&jobs[t]);
         else pthread_create(&tid[t], NULL, batch_worker, &jobs[t]);

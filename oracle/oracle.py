@@ -48,6 +48,9 @@ def lib():
         L.ck_oracle_xxh3_64.restype = ctypes.c_uint64
         L.ck_oracle_xxh3_64.argtypes = [u8p, ctypes.c_size_t]
         L.ck_oracle_canonicalize_batch.argtypes = [u8p, u64p, ctypes.c_uint64, u8p, u64p, ctypes.c_int]
+        L.ck_oracle_canonicalize_batch_nth.argtypes = [u8p, u64p, ctypes.c_uint64, u8p, ctypes.c_int]
+        L.ck_oracle_lmsr_index_nth.restype = ctypes.c_size_t
+        L.ck_oracle_lmsr_index_nth.argtypes = [u8p, ctypes.c_size_t]
         L.ck_oracle_uniq_first_seen.argtypes = [u64p, ctypes.c_uint64, u64p]
         L.ck_oracle_synth_fill.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, u8p]
         L.ck_oracle_complement.restype = ctypes.c_uint8
@@ -102,6 +105,22 @@ def normalize(s):
 def xxh3_64(s):
     b, n = _buf(s)
     return int(lib().ck_oracle_xxh3_64(ctypes.addressof(b), n))
+
+
+def lmsr_index_nth(s):
+    """lmsr_index with the reference's chars().nth() access cost (same answer, quadratic time)."""
+    b, n = _buf(s)
+    return lib().ck_oracle_lmsr_index_nth(ctypes.addressof(b), n)
+
+
+def canonicalize_batch_nth(bytes_arr, offsets, threads=1):
+    """canonicalize_batch through the quadratic cost model of the reference as written; returns out_bytes."""
+    bytes_arr = np.ascontiguousarray(bytes_arr, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = np.empty(max(len(bytes_arr), 1), dtype=np.uint8)
+    lib().ck_oracle_canonicalize_batch_nth(bytes_arr.ctypes.data if len(bytes_arr) else None, offsets.ctypes.data, len(offsets) - 1,
+                                           out.ctypes.data, int(threads))
+    return out[:len(bytes_arr)]
 
 
 def canonicalize_batch(bytes_arr, offsets, want_bytes=True, want_hash=False, threads=1):

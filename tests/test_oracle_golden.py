@@ -74,6 +74,24 @@ def test_lmsr_index_matches_naive_small_alphabets():
         assert O.lmsr_index(bytes(s)) == O.lmsr_index_simple(bytes(s)), s
 
 
+def test_quadratic_cost_model_gives_the_same_answers():
+    """ck_oracle_lmsr_index_nth / canonicalize_batch_nth (bench.py's reference_faithful_quadratic leg): the reference's
+    chars().nth() access pattern -- same answers as the byte-indexed transcription, only slower."""
+    import numpy as np
+    from tests import seqsets
+    rng = random.Random(7)
+    seqs = []
+    for alpha in (b"AC", b"ACGT", b"-ACGNT"):
+        for _ in range(400):
+            seqs.append(bytes(rng.choice(alpha) for _ in range(rng.randint(1, 80))))
+    seqs += [b"", b"A", b"ATGCA", b"banana", b"ACGT" * 20]
+    for s in seqs:
+        assert O.lmsr_index_nth(s) == O.lmsr_index(s), s
+    data, offs = seqsets.pack(seqs)
+    exp, _ = O.canonicalize_batch(data, offs, True, False, threads=2)
+    assert np.array_equal(O.canonicalize_batch_nth(data, offs, threads=2), exp)
+
+
 def test_idempotence_properties():
     rng = random.Random(3)
     for _ in range(2000):
