@@ -206,7 +206,7 @@ template <int BITS>
 CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t* Er, uint32_t member = 0, uint32_t team = 1)
 {
     constexpr uint32_t S = 32 / BITS;           // bytes consumed per packed word
-    constexpr bool RC_FROM_FWD = BITS == 2;     // 2-bit: the reverse strand is a VIEW of Ef (view_word), never stored
+    constexpr bool RC_FROM_FWD = true;          // the reverse strand is a VIEW of Ef (view_word), never stored (round 3: the 4-bit mode too)
     const uint32_t lane = lane_id();
     const uint32_t nwf = n / S, r = n % S, nwv = nwf + (r ? 1u : 0u);
     uint32_t bad = 0;
@@ -215,21 +215,16 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
     // BASELINE config 4 spent 61 % of its wave cycles in s_waitcnt with the VALU 20 % busy).
     constexpr int U = CK_BUILD_ROWS;
     for (uint32_t w0 = member * 64 * U + lane; w0 < nwv; w0 += team * 64 * U) {
-        u32x4 vf[U], vc[U];
+        u32x4 vf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t w = w0 + 64 * u;
             if (w < nwv) {
                 const bool tail = w >= nwf;
-                // tail words read the last / first S bytes of the record (in bounds: n >= 3S) and are shifted up
+                // tail words read the last S bytes of the record (in bounds: n >= 3S) and are shifted up
                 const uint32_t fa = tail ? n - S : w * S;
-                const uint32_t ra = tail ? 0u : n - S * (w + 1);
-                if (BITS == 2) {
-                    vf[u] = load16(src + fa);
-                } else {
-                    vf[u] = u32x4{ load4(src + fa), load4(src + fa + 4), 0, 0 };
-                    vc[u] = u32x4{ load4(src + ra), load4(src + ra + 4), 0, 0 };
-                }
+                if (BITS == 2) vf[u] = load16(src + fa);
+                else vf[u] = u32x4{ load4(src + fa), load4(src + fa + 4), 0, 0 };
             }
         }
 #pragma unroll
@@ -243,7 +238,6 @@ CK_DEV bool build_packed(const uint8_t* src, uint32_t n, uint32_t* Ef, uint32_t*
                     bad |= miss;
                 } else {
                     Ef[w] = pack4_fwd(vf[u].x, vf[u].y, bad) << sh;
-                    Er[w] = pack4_rc(vc[u].x, vc[u].y) << sh;
                 }
             }
         }
@@ -512,7 +506,7 @@ template <int BITS>
 CK_DEV uint32_t need_dw(uint32_t n)
 {
     constexpr uint32_t S = 32 / BITS;
-    return (BITS == 2 ? 1 : 2) * ((n + S - 1) / S + 2) + (n + 31) / 32 + 1;      // one stored strand in 2-bit mode, two otherwise
+    return (BITS == 8 ? 2 : 1) * ((n + S - 1) / S + 2) + (n + 31) / 32 + 1;      // one stored strand in the 2- and 4-bit modes, two in byte mode
 }
 CK_DEV uint32_t need_dw_strand2(uint32_t n) { return (n + 15) / 16 + 2; }         // 2-bit mode without the candidate bitmask
 
@@ -523,7 +517,7 @@ CK_DEV int canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* sr
                               uint32_t* lds, const uint32_t* lut)
 {
     constexpr uint32_t S = 32 / BITS;
-    constexpr bool RCV = BITS == 2;              // reverse strand = a view of the forward words
+    constexpr bool RCV = BITS != 8;              // reverse strand = a view of the forward words (2- and 4-bit modes)
     const uint32_t nwv = (n + S - 1) / S;
     uint32_t* Ef = lds;
     uint32_t* Er = RCV ? lds : lds + (nwv + 2);

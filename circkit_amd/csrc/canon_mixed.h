@@ -1,0 +1,308 @@
+// canon_mixed.h -- the per-record routines of canon_mixed_kernel: batches of mixed lengths (BASELINE config 4), ONE kernel
+// over all records, one wave per record.
+//
+// Same reference functions as canon_core.h (lib/src/canonicalize.rs:5-63) on their common path only: a record whose
+// minimal 16-symbol key is owned by one position and differs between the strands.  Everything else -- ties, periods,
+// reverse-complement palindromes, gaps, bytes outside ACGTN, records that do not fit the wave's LDS slice -- is appended to
+// the list of LDS stage A, whose kernel carries the general routine.  Keeping the general routine OUT of this kernel is the
+// point: with it inlined next to the hot loops (round 2) the kernel was 14k instructions, spilled 55 SGPRs and a VGPR, and
+// issued 1091 vector instructions per record of config 4.
+//
+// What is different from canon_record_mode<2> (canon_core.h):
+//  * ALIGNED loads.  The strand is built from 16-byte-ALIGNED chunks of the payload (a wave's row = 1 KiB of whole cache
+//    lines; the record-shaped 16-byte loads at the record's own alignment are what held the round-2 kernel at the
+//    4.4 TB/s of a copy of that shape) and stored as it comes: LDS symbol index s = record position + a16, a16 = the
+//    record's offset in its first chunk.  The symbols in front of the record in word 0 and behind it in the last word are
+//    then replaced by the record's own tail / head (periodic extension on BOTH sides, one word more on either side), so
+//    every window that starts anywhere in the stored words is the key of a real rotation.
+//  * ONE scan loop for both strands.  The reverse-complement key that ends where forward word w begins is
+//    funnel(rc(E[w]), rc(E[w-1]), 2b): with R = rc_word(E[w]) both strands' sixteen keys per word come from three aligned
+//    LDS words -- no second pass, no mirrored address arithmetic, no cross-lane traffic.
+//  * Full 16-byte stores only (the last window is pulled back to end at n, as in the register routine).
+//  * NM (batches with N, MODE_ALPHA): N packed as G, canon_record_mode2n's rules (a key with an N is below its true value;
+//    the winner stands if its window is N-free, or by the prefix rule) -- but the N are kept as a LIST of record positions
+//    instead of a bitmask: the scans never look at them, the output is written as if they were G / C and patched behind.
+#pragma once
+#include "canon_core.h"
+#include "canon_fast.h"
+#include "canon_stream.h"
+
+namespace ck {
+
+// LDS dwords of the lean routine's strand for a record of n symbols (any alignment): pre-extension word, ceil((15 + n) / 16)
+// strand words, post-extension word, one word more (NM: the N list's counter).  NM: what is left of the slice behind it is
+// the N list, one 16-bit record position per N.
+CK_DEV uint32_t lean_strand_dw(uint32_t n) { return 1 + (n + 30) / 16 + 2; }
+
+struct LeanGeom { uint32_t a16, n, T, nW; };      // T = a16 + n: LDS symbol index of the record's end; nW = strand words
+
+// the 16 symbols at LDS symbol index s (first in the top bits); E[-1] .. E[nW] are valid
+CK_DEV uint32_t lean_window(const uint32_t* E, int32_t s) { return funnel(E[s >> 4], E[(s >> 4) + 1], ((uint32_t)s & 15) * 2); }
+
+// Strand from aligned chunks; returns false when a chunk holds a byte outside the alphabet (the first and last chunk also
+// hold the neighbours' bytes: a stranger there sends the record to stage A for nothing, which is harmless).
+// NM: N is packed as G and its record position appended to the wave's N LIST (nl: 16-bit entries, nl_cap of them, the
+// counter *nl_count zeroed by the caller) -- with N at 1 % that is a 50th of a bitmask's LDS, so a record of config 4's
+// 20 kb still fits a slice of seven workgroups per CU; what the list cannot hold is stage A's (its mode keeps a bitmask).
+// Nothing of the routine's scans ever looks at the list: it is read at the winning window and behind the output.
+template <bool NM>
+CK_DEV bool lean_build(const uint8_t* base, const LeanGeom& g, uint32_t* E, uint16_t* nl, uint32_t nl_cap, uint32_t* nl_count)
+{
+    const uint32_t lane = lane_id();
+    uint32_t bad = 0;
+    constexpr int U = CK_BUILD_ROWS;
+    for (uint32_t w0 = lane; w0 < g.nW; w0 += 64 * U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w = w0 + 64 * u;
+            if (w < g.nW) v[u] = load16(base + 16 * (uint64_t)w);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t w = w0 + 64 * u;
+            if (w < g.nW) {
+                uint32_t nm = 0, miss = 0;
+                if constexpr (NM) E[w] = fast_pack_n(v[u], nm, miss);
+                else E[w] = fast_pack(v[u], miss);
+                bad |= miss;
+                if constexpr (NM) {
+                    while (nm) {                                          // (bit 15 = the chunk's first symbol)
+                        const uint32_t i = (uint32_t)clz32(nm) - 16;
+                        nm &= ~(0x8000u >> i);
+                        const uint32_t q = 16 * w + i - g.a16;            // record position; the neighbours' bytes fall outside [0, n)
+                        if (q < g.n) {
+                            const uint32_t k = lds_atomic_inc(nl_count);
+                            if (k < nl_cap) nl[k] = (uint16_t)q;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return ballot(bad != 0) == 0;
+}
+
+// Periodic extension on both sides (see the file comment); a handful of lanes, every value computed from the words as
+// built before any is stored.
+CK_DEV void lean_extend(const LeanGeom& g, uint32_t* E)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t jl = g.nW - 1, rl = g.T - 16 * jl;                    // last word, its symbols that belong to the record (1..16)
+    uint32_t val = 0, dst = 0;
+    bool on = false;
+    if (lane == 0) {                // word 0: its first a16 symbols become the record's last a16 (LDS indices n .. T)
+        const uint32_t w0 = E[0];
+        val = g.a16 ? bfi(~(0xFFFFFFFFu >> (2 * g.a16)), lean_window(E, (int32_t)g.n), w0) : w0;
+        dst = 0; on = true;
+    } else if (lane == 1) {         // E[-1]: the 16 symbols in front of LDS index 0 = record positions n - 16 - a16 .., at LDS n - 16
+        val = lean_window(E, (int32_t)g.n - 16);
+        dst = ~0u; on = true;
+    } else if (lane == 2) {         // last word: behind its rl record symbols the record's head (LDS index a16 ..)
+        const uint32_t wl = E[jl];
+        val = rl < 16 ? bfi(~(0xFFFFFFFFu >> (2 * rl)), wl, lean_window(E, (int32_t)g.a16) >> (2 * rl)) : wl;
+        dst = jl; on = true;
+    } else if (lane == 3) {         // E[nW]: LDS indices 16 nW .. = the same symbols one period earlier
+        val = lean_window(E, (int32_t)(16 * g.nW - g.n));
+        dst = g.nW; on = true;
+    }
+    wave_sync();
+    if (on) { if (dst == ~0u) E[-1] = val; else E[dst] = val; }
+    wave_sync();
+}
+
+// per-lane running minimum over the lane's words: key, the word that holds it first, how many of the lane's words hold it;
+// SECOND (the N build's prefix rule): the smallest minimum among the lane's OTHER words
+struct LeanBest { uint32_t key = ~0u, word = 0, ties = 0, second = ~0u; };
+template <bool SECOND>
+CK_DEV void lean_update(LeanBest& b, uint32_t m, uint32_t w)
+{
+    if constexpr (SECOND) {
+        const uint32_t hi = m > b.key ? m : b.key;
+        b.second = hi < b.second ? hi : b.second;
+    }
+    const bool lt = m < b.key || b.ties == 0;
+    b.ties = lt ? 1u : b.ties + (m == b.key ? 1u : 0u);
+    b.word = lt ? w : b.word;
+    b.key = lt ? m : b.key;
+}
+
+// the keys that start (forward) / end (reverse) in word j, one per lane & 15: forward key at LDS index 16 j + b, reverse key
+// of the forward window at LDS index 16 j - b
+CK_DEV uint32_t lean_key_at(const uint32_t* E, uint32_t j, uint32_t b, bool fwd)
+{
+    const uint32_t hi = fwd ? E[j] : rc_word<2>(E[j]), lo = fwd ? E[j + 1] : rc_word<2>(E[(int32_t)j - 1]);
+    return funnel(hi, lo, 2 * b);
+}
+
+// One record of more than FAST_MAX_N symbols in the wave's slice.  0: done; 1: not this routine's alphabet (stage A is told);
+// 2: pure as far as seen, but a tie / equal strands / no room (stage A's general routine).
+#ifndef CK_LEAN_MIN_PREFIX
+#define CK_LEAN_MIN_PREFIX 6      // prefix rule: with fewer deciding symbols than this some other rotation shares them anyway (4^6 against ~10^4 rotations)
+#endif
+template <bool NM>
+CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uint32_t n, uint64_t payload_end, uint32_t* slice,
+                             const uint32_t* lut)
+{
+    const uint32_t lane = lane_id();
+    LeanGeom g;
+    g.a16 = ((uint32_t)(uintptr_t)a.bytes + (uint32_t)off) & 15;
+    g.n = n; g.T = g.a16 + n; g.nW = (g.T + 15) >> 4;
+    // the aligned chunks must lie inside the payload: not in front of it (a misaligned payload's first record), not
+    // behind it (the batch's last record(s))
+    if (off < g.a16 || off - g.a16 + 16ull * g.nW > payload_end) return 2;
+    const uint32_t strand_dw = lean_strand_dw(n);
+    if (strand_dw > a.slice_dw || (NM && n > 0xFFFFu)) return 2;
+    uint32_t* E = slice + 1;
+    uint32_t* nl_count = E + g.nW + 1;                                    // (the strand's spare word)
+    uint16_t* nl = reinterpret_cast<uint16_t*>(slice + strand_dw);
+    const uint32_t nl_cap = 2 * (a.slice_dw - strand_dw);
+    if constexpr (NM) {
+        if (lane == 0) *nl_count = 0;
+        wave_sync();
+    }
+    if (!lean_build<NM>(a.bytes + (off - g.a16), g, E, nl, nl_cap, nl_count)) return 1;
+    lean_extend(g, E);                                                    // (its wave_sync also publishes the list)
+    const uint32_t n_n = NM ? *nl_count : 0u;
+    if (NM && n_n > nl_cap) return 1;                                     // more N than the list holds: stage A's bitmask mode
+    // both strands' minimal keys in one pass over the words
+    LeanBest bF, bC;
+    for (uint32_t w = lane; w < g.nW; w += 64) {
+        const uint32_t cur = E[w], nxt = E[w + 1], prv = E[(int32_t)w - 1];
+        lean_update<NM>(bF, word_min_key<2>(cur, nxt), w);
+        lean_update<NM>(bC, word_min_key<2>(rc_word<2>(cur), rc_word<2>(prv)), w);
+    }
+    uint32_t MF, MC;
+    wave_min2_u32(bF.key, bC.key, MF, MC);
+    if (MF == MC) return 2;                         // equal minimal keys (lib/src/canonicalize.rs:58-62 needs the full comparison)
+    const bool fwd = MF < MC;
+    const uint32_t M = fwd ? MF : MC;
+    const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bties = fwd ? bF.ties : bC.ties;
+    const uint64_t owners = ballot(bties != 0 && bkey == M);
+    uint64_t hm = owners;
+    if (ballot(bties > 1 && bkey == M) != 0 || popc64(hm) > 3) return 2;
+    // the owners: one position, possibly seen again in the extension at either end (same record position)
+    int32_t Q = -1;
+    while (hm) {
+        const uint32_t l = (uint32_t)ffs64(hm);
+        hm &= hm - 1;
+        const uint32_t j = readlane(bword, l);
+        const uint32_t key = lean_key_at(E, j, lane & 15, fwd);
+        const uint64_t pm = ballot(lane < 16 && key == M);
+        if (popc64(pm) != 1) return 2;
+        const int32_t b = ffs64(pm);
+        int32_t q = (fwd ? (int32_t)(16 * j) + b : (int32_t)(16 * j) - b) - (int32_t)g.a16;     // record position of the forward window
+        q = q < 0 ? q + (int32_t)n : (q >= (int32_t)n ? q - (int32_t)n : q);
+        if (Q >= 0 && q != Q) return 2;
+        Q = q;
+    }
+    // rotation index on the winning strand; the forward window behind reverse position p starts at n - 16 - p
+    const uint32_t idx = fwd ? (uint32_t)Q : (uint32_t)((int32_t)n - 16 - Q < 0 ? 2 * (int32_t)n - 16 - Q : (int32_t)n - 16 - Q);
+    if constexpr (NM) {
+        // An N inside the winning window -- the forward positions Q .. Q + 15 on either strand -- is where the packed key
+        // differs from the true one: canon_record_mode2n's prefix rule (canon_core.h).  Offset of the first N in the
+        // winner's own reading direction: d on the forward strand, 15 - d on the reverse one.
+        uint32_t first = 16;
+        for (uint32_t k = lane; k < n_n; k += 64) {
+            const int32_t d0 = (int32_t)nl[k] - Q, d = d0 < 0 ? d0 + (int32_t)n : d0;
+            if (d < 16) { const uint32_t o = fwd ? (uint32_t)d : 15u - (uint32_t)d; first = o < first ? o : first; }
+        }
+        first = wave_min_u32(first);
+        if (first < 16) {
+            const uint32_t plen = fwd ? first + 1 : first;
+            if (plen < CK_LEAN_MIN_PREFIX) return 1;
+            // "No other rotation of either strand shares the winner's first plen packed symbols" = no other key is <= thr (M
+            // is the smallest of all).  The scan has kept every lane's smallest word minimum on both strands and, on top, the
+            // smallest among its OTHER words: nothing but the owner words may reach down to thr, and inside them only the
+            // winner itself -- decided without another pass over the strand.
+            const uint32_t sh = 32 - 2 * plen, thr = M | (sh ? 0xFFFFFFFFu >> (32 - sh) : 0u);
+            const bool mine = ((owners >> lane) & 1) != 0;
+            const uint32_t lowest_other = fwd ? bC.key : bF.key, lowest_w = mine ? (fwd ? bF.second : bC.second) : bkey;
+            if (ballot(lowest_other <= thr || lowest_w <= thr) != 0) return 1;
+            for (uint64_t h2 = owners; h2; h2 &= h2 - 1) {
+                const uint32_t j = readlane(bword, (uint32_t)ffs64(h2));
+                if (popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) return 1;
+            }
+        }
+    }
+    if (a.out_bytes) {
+        uint8_t* out = a.out_bytes + off;
+        for (uint32_t w = lane; 16 * w < n; w += 64) {
+            const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16;              // the last window is pulled back to end at n
+            uint32_t p = idx + o;
+            p = p >= n ? p - n : p;
+            // LDS index of the forward window behind the 16 output symbols
+            const uint32_t s = (fwd ? p : (p + 16 <= n ? n - 16 - p : 2 * n - 16 - p)) + g.a16;
+            const uint32_t x = lean_window(E, (int32_t)s);
+            store16(out + o, fast_decode(lut, fwd ? x : rc_word<2>(x)));
+        }
+        if constexpr (NM) {
+            if (n_n) {
+                // the decoded G (forward) / C (reverse) of every listed position becomes N: single-byte stores BEHIND the
+                // 16-byte stores that cover the same bytes (vmcnt(0): those have been performed)
+                wave_sync();
+                vmem_wait<0>();
+                for (uint32_t k = lane; k < n_n; k += 64) {
+                    const int32_t q = (int32_t)nl[k], p = fwd ? q : (int32_t)n - 1 - q, o0 = p - (int32_t)idx, o = o0 < 0 ? o0 + (int32_t)n : o0;
+                    out[o] = 'N';
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// a record of 48..1008 symbols over ACGTN through the register routine, 16 bytes per lane straight from memory (the
+// rescue pass's rescue_one without the list): the N-mask variant of fast_canon, then the 4-bit routine for what it refuses
+CK_DEV bool rescue_direct_n(const CanonArgs& a, const uint32_t* lut, RescueState<false, false>& st, uint32_t rec, uint64_t off, uint64_t len)
+{
+    if (len > FAST_MAX_N || !fast_eligible((uint32_t)len)) return false;
+    const uint32_t n = (uint32_t)len, nwf = n >> 4, t = lane_id();
+    const uint32_t tail_syms = t >= nwf ? (16 - (n & 15)) & 15 : 0;       // the tail lane's symbols move up by this much
+    const u32x4 v = load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t));
+    uint32_t nm, miss;
+    const uint32_t F = fast_pack_n2(v, nm, miss) << (2 * tail_syms);
+    nm <<= 2 * tail_syms;
+    const uint64_t bad = ballot(miss != 0), with_n = ballot(nm != 0);
+    bool done = false;
+    if (bad == 0) {
+        if (with_n == 0) done = fast_canon<false, false>(a, lut, st.hc, st.shape, rec, off, n, F, 0);
+        else done = fast_canon<false, false, false, false, true>(a, lut, st.hc, st.shape, rec, off, n, F, 0, nullptr, nm);
+    }
+    if (!done && (bad | with_n) != 0) {
+        uint32_t H, L, bad4;
+        fast_pack4(v, H, L, bad4);
+        const uint64_t x = ((((uint64_t)H) << 32) | L) << (4 * tail_syms);
+        done = fast_canonw<4, false, false>(a, lut, st.hc, rec, off, n, (uint32_t)(x >> 32), (uint32_t)x, ballot(bad4 != 0) != 0);
+    }
+    return done;
+}
+
+// One wave's share of segment `sgm` of a mode-3 batch: records [sgm * all_seg_cap, ...), every wpb-th from wib on.
+template <bool NM>
+CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint32_t* lut, const uint32_t* lutn, RescueState<false, false>& st,
+                                uint32_t* blk_count, uint32_t sgm, uint32_t wib, uint32_t wpb, uint64_t payload_end)
+{
+    const uint64_t first = (uint64_t)sgm * a.all_seg_cap;
+    const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap));
+    for (uint32_t i = wib; i < count; i += wpb) {
+        const uint32_t rec = (uint32_t)first + i;
+        const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
+        bool not_acgt = false;
+        if (len <= FAST_MAX_N) {
+            if (len >= FAST_MIN_N) {
+                if constexpr (NM) { if (rescue_direct_n(a, lut, st, rec, off, len)) continue; not_acgt = true; }
+                else { if (rescue_direct<false, false>(a, lut, st, rec, off, len, not_acgt)) continue; }
+            }
+        } else if (len < (1ull << 31)) {
+            const int r = canon_lean_record<NM>(a, rec, off, (uint32_t)len, payload_end, slice, lut);
+            wave_sync();                                    // every lane is done with the slice before the next record's build
+            if (r == 0) continue;
+            not_acgt = NM || r == 1;
+        }
+
+        defer_record(a, blk_count, sgm, rec, not_acgt);
+    }
+}
+
+}  // namespace ck

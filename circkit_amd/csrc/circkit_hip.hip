@@ -12,6 +12,7 @@
 #include "canon_core.h"
 #include "canon_fast.h"
 #include "canon_stream.h"
+#include "canon_mixed.h"
 #include "fasta_host.h"
 #ifndef CK_FAST_WPE
 #define CK_FAST_WPE 8     // min waves per SIMD the streaming kernel is compiled for (two 16-wave workgroups per CU: <= 64 VGPRs)
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
-    if (!AUX && !ALPHA && !HASH && (mode & 3) == 3) return;              // ... or canon_mixed_kernel
+    if (!AUX && !HASH && (mode & 3) == 3) return;                        // ... or canon_mixed_kernel (either alphabet)
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
     const bool all_records = (mode & 3) == 3;                           // the streaming kernel stood this batch out
     if (!all_records) {
@@ -359,18 +360,22 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
     if (threadIdx.x == 0 && passed_on > walked) *tiers_busy = 1;
 }
 
-// Batches of mixed lengths (mode 3: the streaming kernel stands them out), pure ACGT: ONE kernel walks all records, four
-// waves per workgroup with a tier-A slice each.  A record of 48..1008 bases takes the register routine straight from
-// memory (what the rescue pass did for such a batch), every other record the general LDS routine (what tier A did with the
-// rescue pass's list), so the latency-bound short records and the bandwidth-bound long ones share the CUs instead of
-// following each other in two launches with a list in between.  Segment s = records [s * all_seg_cap, (s + 1) * all_seg_cap);
-// what the slice cannot hold goes to segment s of the list tier A consumes.  Batches that also want the XXH3 keep the
-// two-launch path: with the fused hash next to the LDS routine this kernel needed ~115 VGPRs (spills at any useful occupancy).
-__global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out,
-                                                                      uint32_t* tiers_busy)
+// Batches of mixed lengths (mode 3: the streaming kernel stands them out): ONE kernel walks all records, four waves per
+// workgroup with a stage-A slice each (canon_mixed.h).  A record of 48..1008 bases takes the register routine straight from
+// memory, a longer one the LEAN LDS routine -- aligned chunks, one scan loop for both strands, the unique-minimum path only;
+// the latency-bound short records and the bandwidth-bound long ones share the CUs.  Everything the lean routines do not
+// decide (ties, palindromes, strangers in the alphabet, records beyond the slice) goes to segment s of the list stage A
+// consumes, whose kernel carries the general routine and the team mode.  Segment s = records [s * all_seg_cap, (s + 1) *
+// all_seg_cap).  NM: the build for batches whose mode carries MODE_ALPHA (N packed as G + a mask bit per symbol).
+// Batches that also want the XXH3, the rotation index or the strand keep the rescue pass + stage A.
+// amdgpu_num_vgpr(36): on gfx90a+ the attribute counts in the unified VGPR + AGPR file at twice the value -- 72 registers,
+// seven waves per SIMD, as __launch_bounds__(256, 7) would give, but WITHOUT that bound's cut of the scalar registers to 94
+// (the trap handler's 16 are taken off 800 / 7 before rounding down): 102 are addressable at that occupancy.
+template <bool NM>
+__device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out, uint32_t* tiers_busy)
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
-    if ((mode & 3) != 3 || (mode & MODE_ALPHA)) return;
+    if ((mode & 3) != 3 || ((mode & MODE_ALPHA) != 0) != NM) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + 4 * a.slice_dw;
@@ -381,25 +386,32 @@ __global__ __launch_bounds__(256, CK_TIER_WPE) void canon_mixed_kernel(ck::Canon
     ck::RescueState<false, false> st;
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     uint32_t* slice = lds + wib * a.slice_dw;
+    const uint64_t payload_end = a.offsets[a.n_records];
     uint32_t passed_on = 0, walked = 0;
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
-        const uint64_t first = (uint64_t)sgm * a.all_seg_cap;
-        const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap));
-        for (uint32_t i = wib; i < count; i += 4) {
-            const uint32_t rec = (uint32_t)first + i;
-            const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
-            bool not_acgt = false;
-            if (ck::rescue_direct<false, false>(a, lut, st, rec, off, len, not_acgt)) continue;
-            if (!ck::canon_record(a, rec, slice, lut, lutn, not_acgt)) ck::defer_record(a, blk_count, sgm, rec, not_acgt);
-            ck::wave_sync();
-        }
+        ck::canon_mixed_segment<NM>(a, slice, lut, lutn, st, blk_count, sgm, wib, 4, payload_end);
         __syncthreads();
-        ck::team_pass(a, lds, lut, nullptr, blk_count, sgm, wib, 4);      // (pure-ACGT batches: the odd record with an N waits for tier A's N-mask team)
         if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
     }
     if (threadIdx.x == 0 && passed_on > walked) *tiers_busy = 1;
+}
+#ifndef CK_MIXED_NM_VGPR
+#define CK_MIXED_NM_VGPR 36
+#endif
+#ifndef CK_MIXED_N_SLICE
+#define CK_MIXED_N_SLICE 1368     // dwords per wave of canon_mixed_n_kernel: the most that still leaves seven workgroups per CU
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(36))) void canon_mixed_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode,
+                                                                                             uint32_t* mode_out, uint32_t* tiers_busy)
+{
+    canon_mixed_body<false>(a, mode_word, host_mode, mode_out, tiers_busy);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(CK_MIXED_NM_VGPR))) void canon_mixed_n_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode,
+                                                                                                             uint32_t* mode_out, uint32_t* tiers_busy)
+{
+    canon_mixed_body<true>(a, mode_word, host_mode, mode_out, tiers_busy);
 }
 
 // GH: the fused XXH3 is finished per 16-record group by one wave (canon_fast.h group_hash_*): 18.2 KiB more LDS, which
@@ -1059,8 +1071,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         uint32_t* mode_out = c->d_mode;               // straight into pinned host memory: no copy-back, no event
 #endif
         // both alphabets' builds unless the host has decided; the one the mode does not name returns at once
-        const bool mixed_has_it = host_mode && !aux && !d_hash && (host_mode & 3) == 3 && !(host_mode & MODE_ALPHA);
-        const bool lean = (!host_mode || !(host_mode & MODE_ALPHA)) && !mixed_has_it, alpha = !host_mode || (host_mode & MODE_ALPHA);
+        const bool mixed_has_it = host_mode && !aux && !d_hash && (host_mode & 3) == 3;
+        const bool lean = (!host_mode || !(host_mode & MODE_ALPHA)) && !mixed_has_it, alpha = (!host_mode || (host_mode & MODE_ALPHA)) && !mixed_has_it;
         if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         else if (d_hash) {
             if (lean) hipLaunchKernelGGL((canon_rescue_kernel<true, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
@@ -1070,19 +1082,28 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         }
     }
-    if (!aux && !d_hash && (!host_mode || ((host_mode & 3) == 3 && !(host_mode & MODE_ALPHA)))) {
-        // mode 3, pure ACGT: canon_mixed_kernel takes every record (the rescue pass above stood out); same lists, same
-        // segments.  One workgroup per segment when the previous batch was such a batch, else a small walking grid.
-        const bool was_mixed = host_mode ? true : ((*c->h_mode & 3) == 3 && !(*c->h_mode & MODE_ALPHA));
-        const unsigned grid = was_mixed ? nseg : (nseg < (unsigned)N_CU * CK_RESCUE_BPC ? nseg : (unsigned)N_CU * CK_RESCUE_BPC);
-        a.slice_dw = TIER_DW[0];
-        const size_t shmem = (4 * TIER_DW[0] + TIER_EXTRA_DW) * 4;
+    if (!aux && !d_hash && (!host_mode || (host_mode & 3) == 3)) {
+        // mode 3: canon_mixed_kernel takes every record (the rescue pass above stood out); same lists, same segments.  Both
+        // alphabets' builds unless the host has decided; one workgroup per segment for the build the previous batch used,
+        // a small walking grid for the other (it returns at once unless the expectation was wrong).
+        const uint32_t seen = *c->h_mode;
+        const unsigned walking = nseg < (unsigned)N_CU * CK_RESCUE_BPC ? nseg : (unsigned)N_CU * CK_RESCUE_BPC;
 #ifdef CK_NO_PINNED_MODE
         uint32_t* mode_out = c->d_counters + 6;
 #else
         uint32_t* mode_out = c->d_mode;
 #endif
-        hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+        for (uint32_t nm = 0; nm < 2; ++nm) {
+            if (host_mode && ((host_mode & MODE_ALPHA) != 0) != (nm != 0)) continue;
+            const bool expected = host_mode ? true : ((seen & 3) == 3 && ((seen & MODE_ALPHA) != 0) == (nm != 0));
+            const unsigned grid = expected ? nseg : walking;
+            // the N build keeps a list of the record's N positions behind the strand: a slightly bigger slice (still seven
+            // workgroups = 28 waves per CU), so that a 20 kb record of config 4 has room for the ~200 it holds at 1 %
+            a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
+            const size_t shmem = (4 * a.slice_dw + TIER_EXTRA_DW) * 4;
+            if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+        }
     }
     const bool tiers_idle = c->h_mode[1] == 1;       // the previous batch's tiers found (next to) nothing: small grids for this one
     // (What the idle tiers cost live, measured by not launching them: 82 us of the 3.70 ms headline step, 116 us of uniq's

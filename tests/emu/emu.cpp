@@ -136,10 +136,20 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 #include "../../circkit_amd/csrc/canon_core.h"
 #include "../../circkit_amd/csrc/canon_fast.h"
 #include "../../circkit_amd/csrc/canon_stream.h"
+#include "../../circkit_amd/csrc/canon_mixed.h"
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
 struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false, solo = true; };
+void mixed_body(void* p)         // one fiber of a 4-wave workgroup of canon_mixed_kernel<NM> (NM = the batch's MODE_ALPHA)
+{
+    Launch* L = (Launch*)p;
+    const uint32_t wib = ck::emu::cur_wave();
+    ck::RescueState<false, false> st;
+    const uint64_t payload_end = L->a.offsets[L->a.n_records];
+    if (L->alpha) ck::canon_mixed_segment<true>(L->a, L->lds + wib * L->a.slice_dw, L->lut, L->lutn, st, L->blk_count, L->block, wib, 4, payload_end);
+    else ck::canon_mixed_segment<false>(L->a, L->lds + wib * L->a.slice_dw, L->lut, L->lutn, st, L->blk_count, L->block, wib, 4, payload_end);
+}
 void wave_body(void* p)          // one fiber of a 4-wave workgroup of the LDS tier (canon_kernel<4>)
 {
     Launch* L = (Launch*)p;
@@ -246,10 +256,13 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     uint32_t total_r = 0;
     L.a.list = list_f.data(); L.a.list_count = cnt_f.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1; L.a.all_seg_cap = cap;
     L.a.defer_list = list_r.data(); L.a.defer_count = cnt_r.data(); L.a.out_seg_cap = cap;
+    // launch_canon: a mode-3 batch that wants bytes only is canon_mixed_kernel's (bit 2 of `alpha` selects it here)
+    const bool mixed = all_records && (alpha & 4) && !out_index && !out_strand && !out_hash && !(flags & ck::CK_FLAG_FWD_ONLY);
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;
         L.block = b; L.blk_count = &blk;
-        for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(rescue_body, &L); }
+        if (mixed) { L.a.slice_dw = slice_dw; ck::emu::run_block(mixed_body, &L, 4); }
+        else for (uint32_t w = 0; w < 4; ++w) { L.wib = w; ck::emu::run_wave(rescue_body, &L); }
         cnt_r[b] = blk; total_r += blk;
     }
     if (n_rescued) *n_rescued = total_f - total_r;

@@ -49,7 +49,7 @@ def alpha_rule(data, offsets):
 
 
 def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1, want_aux=True,
-                       base_shift=0, lead=0, alpha=None, solo=True):
+                       base_shift=0, lead=0, alpha=None, solo=True, mixed=False):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
@@ -80,7 +80,7 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data,
                                      idx.ctypes.data if want_aux else None, strand.ctypes.data if want_aux else None,
                                      hs.ctypes.data if want_hash else None,
-                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged), ctypes.byref(nresc), int(bool(alpha)) | (0 if solo else 2))
+                                     slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged), ctypes.byref(nresc), int(bool(alpha)) | (0 if solo else 2) | (4 if mixed else 0))
     assert st >= 0, "emulator rejected the launch (unknown `staged` geometry?)"
     global last_fast_count, last_fused_hash_count, last_rescued_count
     last_rescued_count = nresc.value

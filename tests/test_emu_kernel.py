@@ -497,3 +497,82 @@ def test_register_routine_with_n_mask(staged):
         a, b = int(offs[i]), int(offs[i + 1])
         assert out[a:b].tobytes() == want[i][0], (i, len(s), s[:60])
     assert emu.last_fast_count >= len(seqs) - 70        # the planted near-ties and the batch's last group take the passes behind
+
+
+# ---- canon_mixed_kernel's lean routines (canon_mixed.h): mode-3 batches that want bytes only --------------------------
+def _sprinkle(rng, s, frac, ch=ord("N")):
+    b = bytearray(s)
+    for i in range(len(b)):
+        if rng.random() < frac:
+            b[i] = ch
+    return bytes(b)
+
+
+def _mixed_batch(seed, with_n):
+    import random
+    rng = random.Random(seed)
+    seqs = seqsets.random_mixed(seed + 1, 40, 48, 1008) + seqsets.random_mixed(seed + 2, 30, 1009, 9000) + \
+        seqsets.random_mixed(seed + 3, 6, 1, 47) + [b"", b"ACGT" * 400, b"A" * 3000]
+    for n in (1100, 2500, 4097):                                          # long reverse-complement palindromes, rotations, repeats
+        h = seqsets.rand_seq(rng, n // 2)
+        seqs.append(h + seqsets.revcomp_acgt(h))
+        base = seqsets.rand_seq(rng, n)
+        k = rng.randrange(n)
+        seqs += [base, base[k:] + base[:k], seqsets.revcomp_acgt(base)]
+        u = seqsets.rand_seq(rng, 37)
+        seqs.append(seqsets.rand_seq(rng, 600) + u * 40 + seqsets.rand_seq(rng, 500))
+        seqs.append(seqsets.rand_seq(rng, 700) + b"A" * 40 + seqsets.rand_seq(rng, 900) + b"A" * 40)        # the minimal key twice
+    if with_n:
+        seqs = [_sprinkle(rng, s, 0.01) if i % 5 else s for i, s in enumerate(seqs)]
+        seqs += [_sprinkle(rng, seqsets.rand_seq(rng, 3000), 0.02, ord("-")), _sprinkle(rng, seqsets.rand_seq(rng, 500), 0.3)]
+    rng.shuffle(seqs)
+    return seqs
+
+
+@pytest.mark.parametrize("with_n", [False, True])
+@pytest.mark.parametrize("base_shift,lead", [(0, 0), (5, 0), (0, 7), (11, 13), (15, 1)])
+def test_mixed_kernel_lean_routines(with_n, base_shift, lead):
+    """canon_mixed_kernel<NM> as launch_canon runs it for a mode-3 batch without hash / index outputs: short records
+    through the register routine from memory, longer ones through the lean LDS routine (aligned chunks at every payload
+    alignment, one scan loop for both strands), the rest -- ties, palindromes, gaps, records beyond the slice -- through the
+    list into stage A.  Bytes against the oracle for every record; most records must be the lean routines' own."""
+    seqs = _mixed_batch(4000 + base_shift + 16 * lead, with_n)
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    out, _, _, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=False, staged=0, slice_dw=1280, n_waves=12,
+                                                        alpha=with_n, mixed=True, base_shift=base_shift, lead=lead)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i], (i, len(s), s[:60])
+    assert emu.last_rescued_count >= (60 if not with_n else 50)          # of ~100 records
+
+
+def test_mixed_kernel_prefix_rule_and_extension_edges():
+    """An N planted inside or right behind the minimal window of long records (the prefix rule's count over both strands),
+    minimal windows that straddle the record's end / start (the periodic extension on both sides), at all sixteen
+    alignments of the record in its first chunk."""
+    import random
+    rng = random.Random(77)
+    seqs = []
+    for k in range(48):
+        n = rng.randint(1100, 2600)
+        s = bytearray(seqsets.rand_seq(rng, n, b"CGT"))
+        pos = rng.choice([0, 1, 7, n - 1, n - 9, n - 16, n - 17, n // 2])
+        for i in range(18):
+            s[(pos + i) % n] = ord("A")                                   # the minimal key, wrapping around the end for some
+        if k % 3 == 0:
+            s[(pos + rng.randint(3, 22)) % n] = ord("N")                 # ...with an N inside or just behind it
+        if k % 3 == 1:
+            s = bytearray(seqsets.revcomp_acgt(bytes(s).replace(b"N", b"A")))   # the reverse strand wins
+            s[rng.randrange(n)] = ord("N")
+        seqs.append(bytes(s) + seqsets.rand_seq(rng, k % 16, b"G"))       # shifts the next record's alignment
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    for alpha in (True, False):
+        out, _, _, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=False, staged=0, slice_dw=1280, n_waves=8,
+                                                            alpha=alpha, mixed=True)
+        assert status == 0 and ndef == 0
+        for i, s in enumerate(seqs):
+            a, b = int(offs[i]), int(offs[i + 1])
+            assert out[a:b].tobytes() == want[i], (alpha, i, len(s))

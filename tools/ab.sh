@@ -8,7 +8,7 @@ rounds=$1; shift
 for r in $(seq $rounds); do
   for v in "$@"; do
     export CIRCKIT_LIB=$R/circkit_amd/libcirckit_hip_$v.so     # read by circkit_amd/api.py; the in-tree library stays as built
-    ms=$(python bench.py --steps 10 --warmup 2 --no-cpu ${AB_ARGS} 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['kernel_ms'])")
+    ms=$(python bench.py --steps 10 --warmup 2 --no-cpu --no-e2e --no-copy ${AB_ARGS} 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.readline())['roofline']['kernel_ms'])")
     echo "$v $ms" >> gpurun_out/ab_raw.txt
   done
 done
