@@ -113,7 +113,7 @@ CK_DEV void lean_extend(const LeanGeom& g, uint32_t* E)
 
 // per-lane running minimum over the lane's words: key, the word that holds it first, how many of the lane's words hold it;
 // SECOND (the N build's prefix rule): the smallest minimum among the lane's OTHER words
-struct LeanBest { uint32_t key = ~0u, word = 0, ties = 0, second = ~0u; };
+struct LeanBest { uint32_t key = ~0u, word = 0, ties = 0, second = ~0u, word2 = 0; };     // word2: the second word of the lane that holds the minimum
 template <bool SECOND>
 CK_DEV void lean_update(LeanBest& b, uint32_t m, uint32_t w)
 {
@@ -121,8 +121,11 @@ CK_DEV void lean_update(LeanBest& b, uint32_t m, uint32_t w)
         const uint32_t hi = m > b.key ? m : b.key;
         b.second = hi < b.second ? hi : b.second;
     }
-    const bool lt = m < b.key || b.ties == 0;
-    b.ties = lt ? 1u : b.ties + (m == b.key ? 1u : 0u);
+    const bool lt = m < b.key || b.ties == 0, eq = !lt && m == b.key;
+    // (two words of one lane with the minimum: mostly ONE position seen twice -- in word 0 or 1 and, as its periodic twin, in
+    // the last words, which share a lane when the record is a little longer than a multiple of 1024 symbols)
+    b.word2 = eq ? w : b.word2;
+    b.ties = lt ? 1u : b.ties + (eq ? 1u : 0u);
     b.word = lt ? w : b.word;
     b.key = lt ? m : b.key;
 }
@@ -133,6 +136,72 @@ CK_DEV uint32_t lean_key_at(const uint32_t* E, uint32_t j, uint32_t b, bool fwd)
 {
     const uint32_t hi = fwd ? E[j] : rc_word<2>(E[j]), lo = fwd ? E[j + 1] : rc_word<2>(E[(int32_t)j - 1]);
     return funnel(hi, lo, 2 * b);
+}
+
+// Two rotations whose 16-symbol keys tie -- of one strand, or one of either strand (f1, f2: forward strand?) --, given by the
+// record positions q1, q2 of the forward windows behind their keys: -1 / +1 as the first / second is the smaller rotation,
+// 0 if they are equal (a period; across the strands: a reverse-complement palindrome).  The rotation at forward window q
+// reads on as the windows at q + 16 t (forward strand) / q - 16 t, reverse-complemented (reverse strand).
+// A handful of records per million-record batch of config 4 get here (a minimal 16-mer owned twice: ~1; a minimal 16-mer
+// inside a reverse-complement palindrome of 18+, which both strands then own: ~6) -- and used to cost the batch a one-wave
+// pass of stage A's general routine behind everything else (~40-70 us of a 1.9 ms step).
+CK_DEV int lean_cmp_rot(const uint32_t* E, const LeanGeom& g, bool f1, uint32_t q1, bool f2, uint32_t q2)
+{
+    const uint32_t lane = lane_id();
+    for (uint32_t base = 0; base < g.n; base += 64 * 16) {
+        const uint32_t t = base + 16 * lane;
+        uint32_t x = 0, y = 0;
+        if (t < g.n) {
+            const uint32_t t1 = f1 ? (q1 + t >= g.n ? q1 + t - g.n : q1 + t) : (q1 >= t ? q1 - t : q1 + g.n - t);
+            const uint32_t t2 = f2 ? (q2 + t >= g.n ? q2 + t - g.n : q2 + t) : (q2 >= t ? q2 - t : q2 + g.n - t);
+            x = lean_window(E, (int32_t)(t1 + g.a16));
+            y = lean_window(E, (int32_t)(t2 + g.a16));
+            x = f1 ? x : rc_word<2>(x);
+            y = f2 ? y : rc_word<2>(y);
+        }
+        const uint64_t bal = ballot(x != y);
+        if (bal) {
+            const uint32_t l = (uint32_t)ffs64(bal);
+            return readlane(x, l) < readlane(y, l) ? -1 : 1;
+        }
+    }
+    return 0;
+}
+
+// The record position of the forward window behind one strand's minimal rotation, from the scan's per-lane results (b) and
+// the wave minimum M: mostly one owner, possibly seen again in the extension at either end (same record position).  Several
+// owners (pure build): the smallest of their rotations, as long as they are few and no two of them equal.  -1: stage A's.
+template <bool NM>
+CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint32_t M, const LeanBest& b)
+{
+    const uint32_t lane = lane_id();
+    uint64_t hm = ballot(b.ties != 0 && b.key == M);
+    if (ballot(b.ties > 2 && b.key == M) != 0 || popc64(hm) > 8) return -1;
+    int32_t Q = -1;
+    uint32_t rivals = 0;
+    uint32_t second_round = 0;                      // (the owner lane's second word)
+    while (hm) {
+        const uint32_t l = (uint32_t)ffs64(hm);
+        const uint32_t j = second_round ? readlane(b.word2, l) : readlane(b.word, l);
+        if (!second_round && readlane(b.ties, l) == 2) second_round = 1;
+        else { second_round = 0; hm &= hm - 1; }
+        const uint32_t key = lean_key_at(E, j, lane & 15, fwd);
+        uint64_t pm = ballot(lane < 16 && key == M);
+        if (NM && popc64(pm) != 1) return -1;
+        while (pm) {
+            const int32_t bit = ffs64(pm);
+            pm &= pm - 1;
+            int32_t q = (fwd ? (int32_t)(16 * j) + bit : (int32_t)(16 * j) - bit) - (int32_t)g.a16;     // record position of the forward window
+            q = q < 0 ? q + (int32_t)g.n : (q >= (int32_t)g.n ? q - (int32_t)g.n : q);
+            if (Q < 0) { Q = q; continue; }
+            if (q == Q) continue;
+            if (NM || ++rivals > 8) return -1;
+            const int c = lean_cmp_rot(E, g, fwd, (uint32_t)q, fwd, (uint32_t)Q);
+            if (c == 0) return -1;
+            if (c < 0) Q = q;
+        }
+    }
+    return Q;
 }
 
 // One record of more than FAST_MAX_N symbols in the wave's slice.  0: done; 1: not this routine's alphabet (stage A is told);
@@ -149,8 +218,14 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
     g.a16 = ((uint32_t)(uintptr_t)a.bytes + (uint32_t)off) & 15;
     g.n = n; g.T = g.a16 + n; g.nW = (g.T + 15) >> 4;
     // the aligned chunks must lie inside the payload: not in front of it (a misaligned payload's first record), not
-    // behind it (the batch's last record(s))
-    if (off < g.a16 || off - g.a16 + 16ull * g.nW > payload_end) return 2;
+    // behind it (the batch's last record(s)).  Such a record is built from 16-byte loads at its own alignment instead
+    // (build_packed<2>: the last word re-reads the record's last 16 bytes), i.e. as a record with a16 = 0 -- the pure build
+    // only; the N build leaves it to stage A.
+    const bool inside = off >= g.a16 && off - g.a16 + 16ull * g.nW <= payload_end;
+    if (!inside) {
+        if (NM) return 2;
+        g.a16 = 0; g.T = n; g.nW = (n + 15) >> 4;
+    }
     const uint32_t strand_dw = lean_strand_dw(n);
     if (strand_dw > a.slice_dw || (NM && n > 0xFFFFu)) return 2;
     uint32_t* E = slice + 1;
@@ -161,7 +236,11 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         if (lane == 0) *nl_count = 0;
         wave_sync();
     }
-    if (!lean_build<NM>(a.bytes + (off - g.a16), g, E, nl, nl_cap, nl_count)) return 1;
+    if (inside) {
+        if (!lean_build<NM>(a.bytes + (off - g.a16), g, E, nl, nl_cap, nl_count)) return 1;
+    } else {
+        if (!build_packed<2>(a.bytes + off, n, E, E)) return 1;         // (its own extension behind the end; lean_extend repeats it)
+    }
     lean_extend(g, E);                                                    // (its wave_sync also publishes the list)
     const uint32_t n_n = NM ? *nl_count : 0u;
     if (NM && n_n > nl_cap) return 1;                                     // more N than the list holds: stage A's bitmask mode
@@ -174,28 +253,23 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
     }
     uint32_t MF, MC;
     wave_min2_u32(bF.key, bC.key, MF, MC);
-    if (MF == MC) return 2;                         // equal minimal keys (lib/src/canonicalize.rs:58-62 needs the full comparison)
-    const bool fwd = MF < MC;
-    const uint32_t M = fwd ? MF : MC;
-    const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bties = fwd ? bF.ties : bC.ties;
-    const uint64_t owners = ballot(bties != 0 && bkey == M);
-    uint64_t hm = owners;
-    if (ballot(bties > 1 && bkey == M) != 0 || popc64(hm) > 3) return 2;
-    // the owners: one position, possibly seen again in the extension at either end (same record position)
-    int32_t Q = -1;
-    while (hm) {
-        const uint32_t l = (uint32_t)ffs64(hm);
-        hm &= hm - 1;
-        const uint32_t j = readlane(bword, l);
-        const uint32_t key = lean_key_at(E, j, lane & 15, fwd);
-        const uint64_t pm = ballot(lane < 16 && key == M);
-        if (popc64(pm) != 1) return 2;
-        const int32_t b = ffs64(pm);
-        int32_t q = (fwd ? (int32_t)(16 * j) + b : (int32_t)(16 * j) - b) - (int32_t)g.a16;     // record position of the forward window
-        q = q < 0 ? q + (int32_t)n : (q >= (int32_t)n ? q - (int32_t)n : q);
-        if (Q >= 0 && q != Q) return 2;
-        Q = q;
+    bool fwd = MF < MC;
+    int32_t Q;
+    if (MF == MC) {
+        // equal minimal keys: the two minimal rotations are compared in full (lib/src/canonicalize.rs:58-62: forward only if
+        // strictly smaller; equal = a reverse-complement palindrome, either strand's bytes are the same) -- pure build only
+        if (NM) return 2;
+        const int32_t QF = lean_locate<NM>(E, g, true, MF, bF), QC = lean_locate<NM>(E, g, false, MC, bC);
+        if (QF < 0 || QC < 0) return 2;
+        fwd = lean_cmp_rot(E, g, true, (uint32_t)QF, false, (uint32_t)QC) < 0;
+        Q = fwd ? QF : QC;
+    } else {
+        Q = fwd ? lean_locate<NM>(E, g, true, MF, bF) : lean_locate<NM>(E, g, false, MC, bC);
+        if (Q < 0) return 2;
     }
+    const uint32_t M = fwd ? MF : MC;
+    const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bties = fwd ? bF.ties : bC.ties, bword2 = fwd ? bF.word2 : bC.word2;
+    const uint64_t owners = ballot(bties != 0 && bkey == M);
     // rotation index on the winning strand; the forward window behind reverse position p starts at n - 16 - p
     const uint32_t idx = fwd ? (uint32_t)Q : (uint32_t)((int32_t)n - 16 - Q < 0 ? 2 * (int32_t)n - 16 - Q : (int32_t)n - 16 - Q);
     if constexpr (NM) {
@@ -220,8 +294,9 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
             const uint32_t lowest_other = fwd ? bC.key : bF.key, lowest_w = mine ? (fwd ? bF.second : bC.second) : bkey;
             if (ballot(lowest_other <= thr || lowest_w <= thr) != 0) return 1;
             for (uint64_t h2 = owners; h2; h2 &= h2 - 1) {
-                const uint32_t j = readlane(bword, (uint32_t)ffs64(h2));
+                const uint32_t l = (uint32_t)ffs64(h2), j = readlane(bword, l), j2 = readlane(bword2, l);
                 if (popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) return 1;
+                if (readlane(bties, l) == 2 && popc64(ballot(lane < 16 && lean_key_at(E, j2, lane & 15, fwd) <= thr)) != 1) return 1;
             }
         }
     }
@@ -252,55 +327,92 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
     return 0;
 }
 
-// a record of 48..1008 symbols over ACGTN through the register routine, 16 bytes per lane straight from memory (the
-// rescue pass's rescue_one without the list): the N-mask variant of fast_canon, then the 4-bit routine for what it refuses
-CK_DEV bool rescue_direct_n(const CanonArgs& a, const uint32_t* lut, RescueState<false, false>& st, uint32_t rec, uint64_t off, uint64_t len)
+// A record's offsets and -- if it is one of 48..1008 symbols, the register routine's -- the 16 bytes this lane packs.
+// (Fetching them while the record BEFORE is being processed -- a short record is two dependent round trips, offsets -> bytes,
+// in front of ~500 cycles of work -- was tried: nothing gained on config 4, 1.87 -> 1.89 ms; the CU's 28 waves hide it, and
+// the N build lost 9 % to the registers.)
+struct MixedNext { uint64_t off, len; u32x4 v; };
+CK_DEV MixedNext mixed_fetch(const CanonArgs& a, uint32_t rec)
 {
-    if (len > FAST_MAX_N || !fast_eligible((uint32_t)len)) return false;
-    const uint32_t n = (uint32_t)len, nwf = n >> 4, t = lane_id();
+    MixedNext m;
+    m.off = a.offsets[rec];
+    m.len = a.offsets[rec + 1] - m.off;
+    m.v = u32x4{ 0, 0, 0, 0 };
+    if (m.len >= FAST_MIN_N && m.len <= FAST_MAX_N) {
+        const uint32_t n = (uint32_t)m.len, t = lane_id();
+        m.v = load16(a.bytes + m.off + (t >= (n >> 4) ? n - 16 : 16 * t));      // lanes past the last full word re-read the record's last 16 bytes
+    }
+    return m;
+}
+// a pure-ACGT record of 48..1008 symbols through the register routine (canon_stream.h rescue_direct with the bytes at hand)
+CK_DEV bool mixed_short(const CanonArgs& a, const uint32_t* lut, RescueState<false, false>& st, uint32_t rec, const MixedNext& m, bool& not_acgt)
+{
+    const uint32_t n = (uint32_t)m.len, nwf = n >> 4, t = lane_id();
+    uint32_t miss;
+    uint32_t F = fast_pack(m.v, miss);
+    F <<= t >= nwf ? ((16 - (n & 15)) & 15) * 2 : 0;
+    const uint64_t bad = ballot(miss != 0);
+    not_acgt = bad != 0;
+    return fast_canon<false, false>(a, lut, st.hc, st.shape, rec, m.off, n, F, bad);
+}
+// the same over ACGTN (the rescue pass's rescue_one without the list): the N-mask variant of fast_canon, then the 4-bit
+// routine for what it refuses
+CK_DEV bool mixed_short_n(const CanonArgs& a, const uint32_t* lut, RescueState<false, false>& st, uint32_t rec, const MixedNext& m)
+{
+    const uint32_t n = (uint32_t)m.len, nwf = n >> 4, t = lane_id();
     const uint32_t tail_syms = t >= nwf ? (16 - (n & 15)) & 15 : 0;       // the tail lane's symbols move up by this much
-    const u32x4 v = load16(a.bytes + off + (t >= nwf ? n - 16 : 16 * t));
     uint32_t nm, miss;
-    const uint32_t F = fast_pack_n2(v, nm, miss) << (2 * tail_syms);
+    const uint32_t F = fast_pack_n2(m.v, nm, miss) << (2 * tail_syms);
     nm <<= 2 * tail_syms;
     const uint64_t bad = ballot(miss != 0), with_n = ballot(nm != 0);
     bool done = false;
     if (bad == 0) {
-        if (with_n == 0) done = fast_canon<false, false>(a, lut, st.hc, st.shape, rec, off, n, F, 0);
-        else done = fast_canon<false, false, false, false, true>(a, lut, st.hc, st.shape, rec, off, n, F, 0, nullptr, nm);
+        if (with_n == 0) done = fast_canon<false, false>(a, lut, st.hc, st.shape, rec, m.off, n, F, 0);
+        else done = fast_canon<false, false, false, false, true>(a, lut, st.hc, st.shape, rec, m.off, n, F, 0, nullptr, nm);
     }
     if (!done && (bad | with_n) != 0) {
         uint32_t H, L, bad4;
-        fast_pack4(v, H, L, bad4);
+        fast_pack4(m.v, H, L, bad4);
         const uint64_t x = ((((uint64_t)H) << 32) | L) << (4 * tail_syms);
-        done = fast_canonw<4, false, false>(a, lut, st.hc, rec, off, n, (uint32_t)(x >> 32), (uint32_t)x, ballot(bad4 != 0) != 0);
+        done = fast_canonw<4, false, false>(a, lut, st.hc, rec, m.off, n, (uint32_t)(x >> 32), (uint32_t)x, ballot(bad4 != 0) != 0);
     }
     return done;
 }
 
 // One wave's share of segment `sgm` of a mode-3 batch: records [sgm * all_seg_cap, ...), every wpb-th from wib on.
 template <bool NM>
-CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint32_t* lut, const uint32_t* lutn, RescueState<false, false>& st,
+CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint32_t* lut, RescueState<false, false>& st,
                                 uint32_t* blk_count, uint32_t sgm, uint32_t wib, uint32_t wpb, uint64_t payload_end)
 {
     const uint64_t first = (uint64_t)sgm * a.all_seg_cap;
     const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap));
+#ifdef CK_MIXED_DYNAMIC
+    // the segment's records handed out one at a time (blk_count[1], zeroed with blk_count[0]): no wave waits for the one that drew the long records
+    for (;;) {
+        uint32_t i = 0;
+        if (lane_id() == 0) i = lds_atomic_inc(blk_count + 1);
+        i = uniform(i);
+        if (i >= count) break;
+#else
     for (uint32_t i = wib; i < count; i += wpb) {
+#endif
         const uint32_t rec = (uint32_t)first + i;
-        const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
-        bool not_acgt = false;
-        if (len <= FAST_MAX_N) {
-            if (len >= FAST_MIN_N) {
-                if constexpr (NM) { if (rescue_direct_n(a, lut, st, rec, off, len)) continue; not_acgt = true; }
-                else { if (rescue_direct<false, false>(a, lut, st, rec, off, len, not_acgt)) continue; }
-            }
-        } else if (len < (1ull << 31)) {
+        const MixedNext cur = mixed_fetch(a, rec);
+        const uint64_t off = cur.off, len = cur.len;
+        bool not_acgt = false, tried = false;
+        if (len >= FAST_MIN_N && len <= FAST_MAX_N) {
+            if constexpr (NM) { if (mixed_short_n(a, lut, st, rec, cur)) continue; tried = true; }
+            else { if (mixed_short(a, lut, st, rec, cur, not_acgt)) continue; }
+        }
+        // longer records -- and (pure build) the few short ones the register routine leaves (a tied minimal key, a minimal key
+        // both strands own): the lean LDS routine
+        if (len >= FAST_MIN_N && len < (1ull << 31) && !not_acgt && !tried) {
             const int r = canon_lean_record<NM>(a, rec, off, (uint32_t)len, payload_end, slice, lut);
             wave_sync();                                    // every lane is done with the slice before the next record's build
             if (r == 0) continue;
             not_acgt = NM || r == 1;
         }
-
+        not_acgt = not_acgt || tried;
         defer_record(a, blk_count, sgm, rec, not_acgt);
     }
 }

@@ -380,18 +380,16 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + 4 * a.slice_dw;
     uint32_t* lut = blk_count + 4;
-    uint32_t* lutn = lut + ck::FAST_LUT_DW;
     ck::fast_lut_init(lut, threadIdx.x, 256);
-    ck::fast_lutn_init(lutn, threadIdx.x, 256);
     ck::RescueState<false, false> st;
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     uint32_t* slice = lds + wib * a.slice_dw;
     const uint64_t payload_end = a.offsets[a.n_records];
     uint32_t passed_on = 0, walked = 0;
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
-        if (threadIdx.x == 0) *blk_count = 0;
+        if (threadIdx.x == 0) { blk_count[0] = 0; blk_count[1] = 0; }
         __syncthreads();
-        ck::canon_mixed_segment<NM>(a, slice, lut, lutn, st, blk_count, sgm, wib, 4, payload_end);
+        ck::canon_mixed_segment<NM>(a, slice, lut, st, blk_count, sgm, wib, 4, payload_end);
         __syncthreads();
         if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
     }
@@ -1105,6 +1103,24 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         }
     }
+#ifdef CK_DEBUG_DUMP
+    {   // experiment builds only (tools/build_variant.sh -DCK_DEBUG_DUMP): what the front kernels handed to stage A
+        (void)hipStreamSynchronize(c->stream);
+        std::vector<uint32_t> cnt(nseg);
+        (void)hipMemcpy(cnt.data(), c->d_seg_counts + c->seg_alloc, nseg * 4, hipMemcpyDeviceToHost);
+        uint64_t total = 0; unsigned shown = 0;
+        for (unsigned sg = 0; sg < nseg; ++sg) {
+            total += cnt[sg];
+            for (uint32_t k = 0; k < cnt[sg] && shown < 12; ++k, ++shown) {
+                uint32_t e = 0; uint64_t o[2];
+                (void)hipMemcpy(&e, c->d_lists[1] + (uint64_t)sg * seg_cap + k, 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(o, d_offsets + (e & ck::ENTRY_REC), 16, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[dump] seg %u entry %u: rec %u flag %u len %llu\n", sg, k, e & ck::ENTRY_REC, e >> 31, (unsigned long long)(o[1] - o[0]));
+            }
+        }
+        fprintf(stderr, "[dump] stage A input: %llu records in %u segments\n", (unsigned long long)total, nseg);
+    }
+#endif
     const bool tiers_idle = c->h_mode[1] == 1;       // the previous batch's tiers found (next to) nothing: small grids for this one
     // (What the idle tiers cost live, measured by not launching them: 82 us of the 3.70 ms headline step, 116 us of uniq's
     // 5.26; with the parallel look at the counts in canon_kernel ~40 us remain -- five dependent launches.)

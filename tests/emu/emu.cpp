@@ -147,8 +147,8 @@ void mixed_body(void* p)         // one fiber of a 4-wave workgroup of canon_mix
     const uint32_t wib = ck::emu::cur_wave();
     ck::RescueState<false, false> st;
     const uint64_t payload_end = L->a.offsets[L->a.n_records];
-    if (L->alpha) ck::canon_mixed_segment<true>(L->a, L->lds + wib * L->a.slice_dw, L->lut, L->lutn, st, L->blk_count, L->block, wib, 4, payload_end);
-    else ck::canon_mixed_segment<false>(L->a, L->lds + wib * L->a.slice_dw, L->lut, L->lutn, st, L->blk_count, L->block, wib, 4, payload_end);
+    if (L->alpha) ck::canon_mixed_segment<true>(L->a, L->lds + wib * L->a.slice_dw, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
+    else ck::canon_mixed_segment<false>(L->a, L->lds + wib * L->a.slice_dw, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
 }
 void wave_body(void* p)          // one fiber of a 4-wave workgroup of the LDS tier (canon_kernel<4>)
 {

@@ -576,3 +576,91 @@ def test_mixed_kernel_prefix_rule_and_extension_edges():
         for i, s in enumerate(seqs):
             a, b = int(offs[i]), int(offs[i + 1])
             assert out[a:b].tobytes() == want[i], (alpha, i, len(s))
+
+
+def test_mixed_kernel_settles_a_tied_minimal_key():
+    """The minimal 16-symbol key owned by several positions (pure build): the lean routine compares their rotations itself
+    -- one such record in a million-record batch used to be a one-wave pass of stage A behind everything else.  Planted:
+    the same minimal 16-mer two to five times, followed by different symbols (a run of 17 or 18 A as well: two or three
+    owners side by side); periodic records still move on."""
+    import random
+    rng = random.Random(91)
+    seqs = []
+    for k in range(40):
+        n_runs = rng.randint(2, 5)
+        run = b"A" * (16 if k % 5 else rng.randint(17, 18))
+        parts = []
+        for _ in range(n_runs):
+            parts.append(run + seqsets.rand_seq(rng, rng.randint(200, 900), b"CGT"))
+        s = b"".join(parts)
+        if k % 4 == 0:
+            s = seqsets.revcomp_acgt(s)                                   # the reverse strand wins
+        seqs.append(s + seqsets.rand_seq(rng, k % 16, b"G"))
+    seqs += [seqsets.rand_seq(rng, 700, b"CGT") * 3, b"ACGT" * 500]       # periods: stage A's
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    out, _, _, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=False, staged=0, slice_dw=1280, n_waves=8,
+                                                        alpha=False, mixed=True)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i], (i, len(s))
+    # most tied records are the lean routine's own (not: those of <= 1008 symbols -- the register routine leaves ties to stage
+    # A --, two owners in words of the same lane, the two periodic records)
+    assert emu.last_rescued_count >= 25
+
+
+@pytest.mark.parametrize("with_n", [False, True])
+def test_mixed_kernel_winner_seen_twice_by_one_lane(with_n):
+    """Records a little longer than a multiple of 1024 symbols: the winning window near the record's start is seen again, as
+    its periodic twin, in the last words -- which then belong to the SAME lane as word 0 or 1 (64 words per row).  The
+    lean routine keeps the lane's second owner word; found on the GPU as ~100 records per million of config 4 that went to
+    stage A for nothing (lengths 1021..1034, 2047, 4104, 5131 ...)."""
+    import random
+    rng = random.Random(123)
+    seqs = []
+    for n in list(range(1010, 1075, 3)) + list(range(2040, 2100, 5)) + [3073, 3080, 4104, 5131]:
+        s = bytearray(seqsets.rand_seq(rng, n, b"CGT"))
+        pos = rng.choice([0, 1, 2, 9, 15, 16, 17, n - 1, n - 2, n - 15, n - 16, n - 17, n - 31])
+        for i in range(16):
+            s[(pos + i) % n] = ord("A")
+        if with_n:
+            s[(pos + 40) % n] = ord("N")
+        seqs.append((seqsets.revcomp_acgt(bytes(s).replace(b"N", b"C")) if n % 2 else bytes(s)) + seqsets.rand_seq(rng, n % 16, b"G"))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    out, _, _, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=False, staged=0, slice_dw=1368, n_waves=8,
+                                                        alpha=with_n, mixed=True)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i], (i, len(s))
+    if not with_n:
+        assert emu.last_rescued_count >= len(seqs) - 1                    # (all but the batch's... none: the last record has its own build)
+
+
+def test_mixed_kernel_minimal_key_inside_a_reverse_complement_palindrome():
+    """A minimal 16-mer inside a reverse-complement palindrome of 18 or more (AAAAAATAGCTATTTTTT) is owned by BOTH strands:
+    equal minimal keys, the two rotations are compared in full by the lean routine itself (seen on the GPU: ~6 records per
+    million of config 4).  Whole-record palindromes included (equal rotations: the reverse strand's bytes, identical)."""
+    import random
+    rng = random.Random(321)
+    seqs = []
+    for k in range(30):
+        half = b"A" * rng.randint(6, 9) + seqsets.rand_seq(rng, rng.randint(1, 4), b"ACGT")
+        pal = half + seqsets.revcomp_acgt(half)                          # self reverse-complementary, starts with the A run
+        body = seqsets.rand_seq(rng, rng.randint(1100, 4000), b"CGT")
+        s = body[:len(body) // 3] + pal + body[len(body) // 3:]
+        seqs.append(s + seqsets.rand_seq(rng, k % 16, b"G"))
+    for n in (1200, 2600):
+        h = seqsets.rand_seq(rng, n // 2)
+        seqs.append(h + seqsets.revcomp_acgt(h))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    out, _, _, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=False, staged=0, slice_dw=1280, n_waves=8,
+                                                        alpha=False, mixed=True)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i], (i, len(s))
+    assert emu.last_rescued_count >= 28
