@@ -37,6 +37,11 @@ struct CanonArgs {
     uint8_t* out_strand;         // nullable
     uint64_t* out_hash;          // nullable; XXH3-64 of the canonical bytes (written by the streaming kernel where it can)
     uint8_t* hashed;             // [n_records] set to 1 where out_hash was written; the xxh3 pass does the rest
+    // hash-only batches (out_hash without out_bytes: `uniq` without --canonicalize, src/uniq.rs:55-60): a record whose hash is
+    // not fused leaves its canonical form as a VIEW of the input for the xxh3 pass -- bit 31 = reverse strand, bits 0..30 =
+    // rotation index on that strand OF THE RECORD ITSELF (not the reference-visible out_index, which for the reverse strand
+    // counts from the forward strand's minimal rotation) -- instead of writing bytes nobody has asked for
+    uint32_t* out_view;          // nullable; [n_records]
     // Work lists are SEGMENTED per producing workgroup: a workgroup appends the records it cannot take to its own
     // segment with an LDS counter and publishes the count when it ends -- no global atomics on the data path
     // (one shared counter serialises at ~10 ns per append: 7 ms for the 760k deferrals of BASELINE config 4).
@@ -52,7 +57,6 @@ struct CanonArgs {
     uint32_t slice_dw;           // LDS dwords available to one wave
     uint32_t flags;              // CK_FLAG_*
 };
-constexpr uint32_t CK_FLAG_BYTES_OPTIONAL = 2u;   // out_bytes is a scratch: only records whose hash is NOT fused need their bytes
 constexpr uint32_t CK_FLAG_FWD_ONLY = 1u;   // lmsr(): forward strand only (lib/src/canonicalize.rs:41-47)
 
 
@@ -547,6 +551,7 @@ CK_DEV int canon_record_mode(const CanonArgs& a, uint64_t rec, const uint8_t* sr
         // lmsr_index(revcomp(lmsr(s))) for the reverse strand (rotation by f.idx, modulo the period)
         if (a.out_index) a.out_index[rec] = fwd ? f.idx : (r.idx + f.idx) % f.period;
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+        if (a.out_view) a.out_view[rec] = fwd ? f.idx : (r.idx | 0x80000000u);
     }
     return 0;
 }
@@ -757,6 +762,7 @@ CK_DEV int canon_record_mode2n(const CanonArgs& a, uint64_t rec, const uint8_t* 
     if (lane_id() == 0) {
         if (a.out_index) a.out_index[rec] = fwd ? pos : (pos + fpos) % n;        // unique minimum: period n
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+        if (a.out_view) a.out_view[rec] = fwd ? pos : (pos | 0x80000000u);
     }
     return 0;
 }
@@ -895,6 +901,7 @@ CK_DEV int canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, c
     if (member == 0 && lane == 0) {
         if (a.out_index) a.out_index[rec] = fwd ? pF : (pC + pF) % n;               // unique minima: period n
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+        if (a.out_view) a.out_view[rec] = fwd ? pF : (pC | 0x80000000u);
     }
     block_barrier();                                            // the strand is read to the end before the next record's build
     return 0;
@@ -967,6 +974,7 @@ CK_DEV bool canon_record_team2n(const CanonArgs& a, uint64_t rec, uint32_t* lds,
     if (member == 0 && lane == 0) {
         if (a.out_index) a.out_index[rec] = fwd ? pF : (pC + pF) % n;
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
+        if (a.out_view) a.out_view[rec] = fwd ? pF : (pC | 0x80000000u);
     }
     block_barrier();
     return true;

@@ -335,7 +335,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
     {
         const uint32_t o = sh.out_o;
         const bool hash = HASH && a.out_hash != nullptr && n > 240;     // XXH3's long-input path; shorter: xxh3 pass
-        const bool store = a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL));
+        const bool store = a.out_bytes != nullptr;
         if (store || hash) {
             u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
             if constexpr (NM) {
@@ -366,6 +366,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         if (a.out_index) a.out_index[rec] = fwd ? idx : (idx + iF >= n ? idx + iF - n : idx + iF);
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
+    if (HASH && a.out_view && n <= 240 && t == 0) a.out_view[rec] = fwd ? idx : (idx | 0x80000000u);      // hash not fused: the xxh3 pass reads the view
     return true;
 }
 
@@ -515,7 +516,7 @@ CK_DEV bool fast_canonw(const CanonArgs& a, const uint32_t* lut, const FastHashC
     if (AUX && a.out_index && !fwd) iF = fast2x_locate<BITS>(W0, W1, W0n, ballot(mF0 == MF), ballot(mF1 == MF), MF, n, shv, uF);
     if (bad || tie || !uE || !uF) return false;
     const bool hash = BITS == 2 && HASH && a.out_hash != nullptr;
-    if (a.out_bytes != nullptr && !(hash && (a.flags & CK_FLAG_BYTES_OPTIONAL))) {
+    if (a.out_bytes != nullptr) {
         if (BITS == 2) {
 #pragma unroll
             for (uint32_t k = 0; k < 2; ++k) {
@@ -540,6 +541,7 @@ CK_DEV bool fast_canonw(const CanonArgs& a, const uint32_t* lut, const FastHashC
         if (a.out_index) a.out_index[rec] = fwd ? idx : (idx + iF >= n ? idx + iF - n : idx + iF);
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
+    if (HASH && !hash && a.out_view && t == 0) a.out_view[rec] = fwd ? idx : (idx | 0x80000000u);         // (the 4-bit records: hash not fused)
     return true;
 }
 template <bool HASH, bool AUX>

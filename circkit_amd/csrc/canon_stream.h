@@ -107,7 +107,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     FastShape shape;
     // does every record issue at least one store (bytes, hash, index or its deferral)?  The vmcnt arithmetic below counts
     // on it.  Not with the group merger on a hash-only batch: a record then leaves nothing but LDS writes.
-    const bool stores = GH ? (a.out_bytes && !(a.flags & CK_FLAG_BYTES_OPTIONAL)) : (a.out_bytes || a.out_hash || a.out_index || a.out_strand);
+    const bool stores = GH ? a.out_bytes != nullptr : (a.out_bytes || a.out_hash || a.out_index || a.out_strand);
     const uint32_t* gh_const = GH ? gh + 2 * C::GROUP * GH_STRIDE_DW : nullptr;
     uint32_t c16[C::DPW];
 #pragma unroll

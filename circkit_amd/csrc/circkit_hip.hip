@@ -460,8 +460,10 @@ __global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE
 // XXH3-64 of each record of a CSR batch, one wavefront per record (see xxh3_core.h).  With `hashed` (the flags of
 // the records the streaming kernel hashed itself) a wave takes 64 records at a time, one flag per lane, and only
 // visits the ones still missing -- the pass over an all-hashed batch is one byte load per record.
+// view (hash-only batches): `bytes` is the INPUT payload and record r's canonical form the rotation / reverse complement of it
+// that view[r] names (CanonArgs::out_view, comp = the ctx's complement table) -- nothing was written out as bytes.
 __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const uint64_t* offsets, uint64_t n_records,
-                                                   uint64_t* out, const uint8_t* hashed)
+                                                   uint64_t* out, const uint8_t* hashed, const uint32_t* view, const uint8_t* comp)
 {
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
@@ -498,7 +500,8 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
             const uint32_t l = (uint32_t)ck::ffs64(todo);
             todo &= todo - 1;
             const uint64_t off = ((uint64_t)ck::readlane((uint32_t)(my_off >> 32), l) << 32) | ck::readlane((uint32_t)my_off, l);
-            const uint64_t h = ck::xxh3_64_wave(bytes + off, ck::readlane(my_len, l), xk);
+            const uint32_t len = ck::readlane(my_len, l);
+            const uint64_t h = view ? ck::xxh3_64_wave_view(bytes + off, len, view[base + l], comp, xk) : ck::xxh3_64_wave(bytes + off, len, xk);
             if (ck::lane_id() == 0) out[base + l] = h;
         }
       }
@@ -880,7 +883,7 @@ struct circkit_ctx {
     uint8_t *d_in = nullptr, *d_out = nullptr, *d_strand = nullptr;
     uint64_t* d_off = nullptr; uint32_t* d_idx = nullptr; uint64_t* d_hash = nullptr;
     uint64_t cap_bytes = 0, cap_rec = 0;
-    uint8_t* d_scratch = nullptr; uint64_t cap_scratch = 0;   // canonical bytes of hash-only batches
+    uint32_t* d_view = nullptr; uint64_t cap_view = 0;        // hash-only batches: strand + rotation of the records whose hash is not fused
     uint8_t* d_hashed = nullptr; uint64_t cap_hashed = 0;     // per record: hash already written by the streaming kernel
     // records beyond the last LDS tier run the same per-record code over slices of this global-memory scratch
     // (grow-only; the device API allocates the default on first use, the host API sizes it for the batch's longest record)
@@ -976,19 +979,17 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     int rc = ensure_lists(c, (uint64_t)G * cap + 1024ull * cap, G < 256u ? 256u : G);
     if (rc) return rc;
     if (!c->d_gscratch && (rc = ensure_gscratch(c, c->gscratch_default))) return rc;
+    uint32_t* view = nullptr;
     if (d_hash && !d_out) {
-        // hash-only (uniq without --canonicalize): the canonical bytes go to a ctx-owned scratch the hash kernel
-        // reads back.  Its size is offsets[n], fetched from the device (one small synchronous copy).
-        uint64_t lastoff = 0;
-        CK_HIP(c, hipMemcpyAsync(&lastoff, d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
-        CK_HIP(c, hipStreamSynchronize(c->stream));
-        if (lastoff + 64 > c->cap_scratch) {
-            if (c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = nullptr; c->cap_scratch = 0; }
-            CK_HIP(c, hipMalloc(&c->d_scratch, lastoff + 64));
-            c->cap_scratch = lastoff + 64;
+        // hash-only (uniq without --canonicalize, src/uniq.rs:55-60): no canonical bytes are written anywhere.  A record
+        // whose hash is not fused leaves its canonical form as a view of the input -- strand + rotation, one u32 in a ctx
+        // array sized by n (known here: no look at the device, no synchronisation) -- and the xxh3 pass hashes that view.
+        if (n > c->cap_view) {
+            if (c->d_view) { (void)hipFree(c->d_view); c->d_view = nullptr; c->cap_view = 0; }
+            CK_HIP(c, hipMalloc(&c->d_view, (n + n / 8 + 64) * sizeof(uint32_t)));
+            c->cap_view = n + n / 8 + 64;
         }
-        d_out = c->d_scratch;       // indexed by the same absolute offsets as the input
-        flags |= ck::CK_FLAG_BYTES_OPTIONAL;   // ...and only needed for records whose hash is not fused
+        view = c->d_view;
     }
     if (d_hash) {
         if (n > c->cap_hashed) {
@@ -1006,7 +1007,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
-    a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = d_hash; a.hashed = c->d_hashed;
+    a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = d_hash; a.hashed = c->d_hashed; a.out_view = view;
     a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
     a.list = nullptr; a.list_count = nullptr; a.all_seg_cap = all_cap;
@@ -1169,7 +1170,11 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                            (const uint32_t*)(c->d_counters + 1), c->d_mode + 1);
     }
     if (d_hash) {
-        hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed);
+        // the records whose hash was not fused: from their canonical bytes, or (hash-only batch) from the input through their views
+        if (view) hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_bytes, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed,
+                                     (const uint32_t*)view, (const uint8_t*)c->d_comp);
+        else hipLaunchKernelGGL(xxh3_kernel, dim3(G < 2048u ? G : 2048u), dim3(256), 0, c->stream, d_out, d_offsets, n, d_hash, (const uint8_t*)c->d_hashed,
+                                (const uint32_t*)nullptr, (const uint8_t*)nullptr);
     }
     CK_HIP(c, hipEventRecord(c->ev1, c->stream));
     CK_HIP(c, hipGetLastError());
@@ -1200,7 +1205,7 @@ int launch_single(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offs
         a.slice_dw = (uint32_t)(need < 0xFFFFFFFFull ? need : 0xFFFFFFFFull);
         hipLaunchKernelGGL(canon_global_one_kernel, dim3(1), dim3(64), 0, c->stream, a, c->d_gscratch);
     }
-    if (d_hash) hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, d_out, d_offsets, (uint64_t)1, d_hash, (const uint8_t*)nullptr);
+    if (d_hash) hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, d_out, d_offsets, (uint64_t)1, d_hash, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr);
     CK_HIP(c, hipGetLastError());
     c->timed = false;
     return CIRCKIT_OK;
@@ -1340,7 +1345,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void* ptrs[] = { c->d_comp, c->d_counters, c->d_seg_counts, c->d_in, c->d_out, c->d_strand, c->d_off, c->d_idx, c->d_hash, c->d_table,
-                     c->d_scratch, c->d_hashed, c->d_gscratch };
+                     c->d_view, c->d_hashed, c->d_gscratch };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (uint32_t* p : c->d_lists) if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1513,7 +1518,7 @@ int circkit_xxh3_64(circkit_ctx* c, const uint8_t* s, size_t n, uint64_t* out_ha
     uint64_t off[2] = { 0, (uint64_t)n };
     if (n) CK_HIP(c, hipMemcpyAsync(c->d_in, s, n, hipMemcpyHostToDevice, c->stream));
     CK_HIP(c, hipMemcpyAsync(c->d_off, off, 16, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, c->d_in, c->d_off, (uint64_t)1, c->d_hash, (const uint8_t*)nullptr);
+    hipLaunchKernelGGL(xxh3_kernel, dim3(1), dim3(256), 0, c->stream, c->d_in, c->d_off, (uint64_t)1, c->d_hash, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr);
     CK_HIP(c, hipMemcpyAsync(out_hash, c->d_hash, 8, hipMemcpyDeviceToHost, c->stream));
     CK_HIP(c, hipStreamSynchronize(c->stream));
     return CIRCKIT_OK;
@@ -1527,7 +1532,7 @@ int circkit_xxh3_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint
     CK_HIP(c, hipSetDevice(c->device));
     const uint64_t blocks = (n + 3) / 4;
     const unsigned grid = (unsigned)(blocks < (uint64_t)N_CU * 8 ? blocks : (uint64_t)N_CU * 8);
-    hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_bytes, d_offsets, n, d_hash, (const uint8_t*)nullptr);
+    hipLaunchKernelGGL(xxh3_kernel, dim3(grid), dim3(256), 0, c->stream, d_bytes, d_offsets, n, d_hash, (const uint8_t*)nullptr, (const uint32_t*)nullptr, (const uint8_t*)nullptr);
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
 }

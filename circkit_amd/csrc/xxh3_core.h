@@ -55,49 +55,83 @@ CK_DEV uint64_t xaval64(uint64_t h)
 {
     h ^= h >> 33; h *= XP64_2; h ^= h >> 29; h *= XP64_3; return h ^ (h >> 32);
 }
-CK_DEV uint64_t xmix16(const uint8_t* in, uint32_t so)
+// What is hashed: bytes in memory (XPlain), or -- hash-only batches, `uniq` without `--canonicalize` (src/uniq.rs:45,55-60)
+// -- the canonical record as a VIEW of the input record (XView): rotation `rot` of the record itself or of its reverse
+// complement (bio 1.3.1's table), never written out as bytes.  v[i] = s[(rot + i) mod n], or comp[s[n - 1 - (rot + i) mod n]].
+struct XPlain { const uint8_t* p; };
+struct XView { const uint8_t* s; uint32_t n, rot; bool rc; const uint8_t* comp; };
+CK_DEV uint32_t xr8(const XPlain& r, uint32_t o) { return r.p[o]; }
+CK_DEV uint32_t xr32(const XPlain& r, uint32_t o) { return load4(r.p + o); }
+CK_DEV uint64_t xr64(const XPlain& r, uint32_t o) { return xrd64(r.p + o); }
+CK_DEV uint32_t xr8(const XView& r, uint32_t o)
 {
-    return xfold(xrd64(in) ^ xsec64(so), xrd64(in + 8) ^ xsec64(so + 8));
+    uint32_t q = r.rot + o;
+    q = q >= r.n ? q - r.n : q;
+    return r.rc ? r.comp[r.s[r.n - 1 - q]] : r.s[q];
+}
+CK_DEV uint32_t xr32(const XView& r, uint32_t o) { return xr8(r, o) | (xr8(r, o + 1) << 8) | (xr8(r, o + 2) << 16) | (xr8(r, o + 3) << 24); }
+CK_DEV uint64_t xr64(const XView& r, uint32_t o)
+{
+    uint32_t q = r.rot + o;
+    q = q >= r.n ? q - r.n : q;
+    if (q + 8 <= r.n) {                                     // the eight bytes do not wrap
+        if (!r.rc) return xrd64(r.s + q);
+        const uint64_t x = xrd64(r.s + (r.n - 8 - q));       // source bytes n-1-q-7 .. n-1-q: reversed, complemented
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v |= (uint64_t)r.comp[(x >> (56 - 8 * i)) & 0xFF] << (8 * i);
+        return v;
+    }
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < 8; ++i) v |= (uint64_t)xr8(r, o + i) << (8 * i);
+    return v;
+}
+
+template <class R>
+CK_DEV uint64_t xmix16(const R& in, uint32_t o, uint32_t so)
+{
+    return xfold(xr64(in, o) ^ xsec64(so), xr64(in, o + 8) ^ xsec64(so + 8));
 }
 
 // Lengths <= 240: every lane computes the same scalar recipe (addresses are wave-uniform).
-CK_DEV uint64_t xxh3_short(const uint8_t* in, uint32_t len)
+template <class R>
+CK_DEV uint64_t xxh3_short(const R& in, uint32_t len)
 {
     if (len == 0) return xaval64(xsec64(56) ^ xsec64(64));
     if (len <= 3) {
-        const uint32_t c1 = in[0], c2 = in[len >> 1], c3 = in[len - 1];
+        const uint32_t c1 = xr8(in, 0), c2 = xr8(in, len >> 1), c3 = xr8(in, len - 1);
         const uint32_t comb = (c1 << 16) | (c2 << 24) | c3 | (len << 8);
         return xaval64((uint64_t)comb ^ (uint64_t)(xsec32(0) ^ xsec32(4)));
     }
     if (len <= 8) {
-        const uint64_t i1 = load4(in), i2 = load4(in + len - 4);
+        const uint64_t i1 = xr32(in, 0), i2 = xr32(in, len - 4);
         uint64_t h = (i2 + (i1 << 32)) ^ (xsec64(8) ^ xsec64(16));
         h ^= xrotl(h, 49) ^ xrotl(h, 24);
         h *= XPMX2; h ^= (h >> 35) + len; h *= XPMX2;
         return h ^ (h >> 28);
     }
     if (len <= 16) {
-        const uint64_t lo = xrd64(in) ^ (xsec64(24) ^ xsec64(32)), hi = xrd64(in + len - 8) ^ (xsec64(40) ^ xsec64(48));
+        const uint64_t lo = xr64(in, 0) ^ (xsec64(24) ^ xsec64(32)), hi = xr64(in, len - 8) ^ (xsec64(40) ^ xsec64(48));
         return xaval3((uint64_t)len + xswap64(lo) + hi + xfold(lo, hi));
     }
     if (len <= 128) {
         uint64_t acc = (uint64_t)len * XP64_1;
         if (len > 32) {
             if (len > 64) {
-                if (len > 96) { acc += xmix16(in + 48, 96); acc += xmix16(in + len - 64, 112); }
-                acc += xmix16(in + 32, 64); acc += xmix16(in + len - 48, 80);
+                if (len > 96) { acc += xmix16(in, 48, 96); acc += xmix16(in, len - 64, 112); }
+                acc += xmix16(in, 32, 64); acc += xmix16(in, len - 48, 80);
             }
-            acc += xmix16(in + 16, 32); acc += xmix16(in + len - 32, 48);
+            acc += xmix16(in, 16, 32); acc += xmix16(in, len - 32, 48);
         }
-        acc += xmix16(in, 0); acc += xmix16(in + len - 16, 16);
+        acc += xmix16(in, 0, 0); acc += xmix16(in, len - 16, 16);
         return xaval3(acc);
     }
     uint64_t acc = (uint64_t)len * XP64_1;
     const uint32_t rounds = len / 16;
-    for (uint32_t i = 0; i < 8; ++i) acc += xmix16(in + 16 * i, 16 * i);
+    for (uint32_t i = 0; i < 8; ++i) acc += xmix16(in, 16 * i, 16 * i);
     acc = xaval3(acc);
-    for (uint32_t i = 8; i < rounds; ++i) acc += xmix16(in + 16 * i, 16 * (i - 8) + 3);
-    acc += xmix16(in + len - 16, 136 - 17);
+    for (uint32_t i = 8; i < rounds; ++i) acc += xmix16(in, 16 * i, 16 * (i - 8) + 3);
+    acc += xmix16(in, len - 16, 136 - 17);
     return xaval3(acc);
 }
 
@@ -150,14 +184,15 @@ CK_DEV void xcell_k(uint64_t d0, uint64_t d1, uint64_t s0, uint64_t s1, uint64_t
 // XXH3-64 (seed 0) of in[0, len) computed by one wave; every lane returns the hash.  Long inputs: lane = (stripe,
 // accumulator pair) cell of a 1024-byte block; the loads of up to four blocks and of the last stripe are all issued
 // before the first is consumed (a 1-2 kb record is otherwise three dependent round trips).
-CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len, const XWaveConst& k)
+template <class R>
+CK_DEV uint64_t xxh3_64_wave_r(const R& in, uint32_t len, const XWaveConst& k)
 {
     if (len <= 240) return xxh3_short(in, len);
     const uint32_t lane = lane_id(), j = lane & 3, s = lane >> 2;
     uint64_t a0 = k.i0, a1 = k.i1;
     const uint32_t nb = (len - 1) / 1024;                  // full blocks before the last (partial or full) one
-    const uint8_t* lp = in + len - 64 + 16 * j;
-    const uint64_t ld0 = xrd64(lp), ld1 = xrd64(lp + 8);   // last stripe, in flight with the blocks below
+    const uint32_t last_o = len - 64 + 16 * j;
+    const uint64_t ld0 = xr64(in, last_o), ld1 = xr64(in, last_o + 8);   // last stripe, in flight with the blocks below
     constexpr uint32_t U = 4;
     for (uint32_t b0 = 0; b0 <= nb; b0 += U) {
         uint64_t d0[U], d1[U];
@@ -168,7 +203,7 @@ CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len, const XWaveConst& 
             const uint32_t stripes = b < nb ? 16u : ((len - 1) - 1024 * nb) / 64;
             on[u] = b <= nb && s < stripes;
             d0[u] = d1[u] = 0;
-            if (on[u]) { const uint8_t* p = in + 1024 * b + 16 * lane; d0[u] = xrd64(p); d1[u] = xrd64(p + 8); }
+            if (on[u]) { const uint32_t o = 1024 * b + 16 * lane; d0[u] = xr64(in, o); d1[u] = xr64(in, o + 8); }
         }
 #pragma unroll
         for (uint32_t u = 0; u < U; ++u) {
@@ -193,6 +228,12 @@ CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len, const XWaveConst& 
     }
     return xaval3((uint64_t)len * XP64_1 + t);
 }
+CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len, const XWaveConst& k) { return xxh3_64_wave_r(XPlain{ in }, len, k); }
 CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len) { return xxh3_64_wave(in, len, xwave_const()); }
+// the canonical record as a view of the input record s[0, n): view = rotation | strand << 31 (CanonArgs::out_view)
+CK_DEV uint64_t xxh3_64_wave_view(const uint8_t* s, uint32_t n, uint32_t view, const uint8_t* comp, const XWaveConst& k)
+{
+    return xxh3_64_wave_r(XView{ s, n, view & 0x7FFFFFFFu, (view >> 31) != 0, comp }, n, k);
+}
 
 }  // namespace ck

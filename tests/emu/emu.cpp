@@ -195,11 +195,12 @@ const StreamVariant kStream[] = {
 }
 
 namespace {
-struct HashLaunch { const uint8_t* p; uint32_t n; uint64_t out[64]; };
+struct HashLaunch { const uint8_t* p; uint32_t n; uint64_t out[64]; const uint8_t* comp = nullptr; uint32_t view = 0; };
 void hash_body(void* q)
 {
     HashLaunch* H = (HashLaunch*)q;
-    H->out[ck::lane_id()] = ck::xxh3_64_wave(H->p, H->n);
+    // comp given: the canonical record as a view of the INPUT record (hash-only batches, xxh3_kernel's view branch)
+    H->out[ck::lane_id()] = H->comp ? ck::xxh3_64_wave_view(H->p, H->n, H->view, H->comp, ck::xwave_const()) : ck::xxh3_64_wave(H->p, H->n);
 }
 }
 
@@ -235,6 +236,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a.out_bytes = out_bytes; L.a.out_index = out_index; L.a.out_strand = out_strand; L.a.out_hash = out_hash;
     std::vector<uint8_t> hashed(n_records + 1, 0);
     L.a.hashed = hashed.data();
+    std::vector<uint32_t> view(n_records + 1, 0xDEADBEEFu);       // launch_canon: a hash-only batch (no out_bytes) leaves views
+    L.a.out_view = out_hash && !out_bytes ? view.data() : nullptr;
     L.a.status = &status; L.a.comp_lut = comp; L.a.flags = flags;
     L.a.defer_list = list_f.data(); L.a.defer_count = cnt_f.data(); L.a.out_seg_cap = cap;
     L.lds = lds.data(); L.lut = lut; L.lutn = lutn; L.nblocks = G;
@@ -278,7 +281,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     if (out_hash) {     // the xxh3 pass for whatever the streaming kernel did not hash
         for (uint64_t r = 0; r < n_records; ++r) {
             if (hashed[r]) continue;
-            HashLaunch H{ out_bytes + offsets[r], (uint32_t)(offsets[r + 1] - offsets[r]), {0} };
+            HashLaunch H{ (out_bytes ? out_bytes : bytes) + offsets[r], (uint32_t)(offsets[r + 1] - offsets[r]), {0} };
+            if (!out_bytes) { H.comp = comp; H.view = view[r]; }
             ck::emu::run_wave(hash_body, &H);
             out_hash[r] = H.out[0];
         }

@@ -49,7 +49,7 @@ def alpha_rule(data, offsets):
 
 
 def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False, flags=0, staged=1, want_aux=True,
-                       base_shift=0, lead=0, alpha=None, solo=True, mixed=False):
+                       base_shift=0, lead=0, alpha=None, solo=True, mixed=False, hash_only=False):
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
@@ -77,7 +77,8 @@ def canonicalize_batch(data, offsets, slice_dw=1024, n_waves=3, want_hash=False,
     nfused = ctypes.c_uint32(0)
     nresc = ctypes.c_uint32(0)
     # want_aux=False: no rotation index / strand outputs -- the streaming kernel's leaner builds (see launch_canon)
-    st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, out.ctypes.data,
+    # hash_only: no canonical bytes anywhere (launch_canon with d_hash and without d_out): views + the xxh3 pass over them
+    st = _lib.emu_canonicalize_batch(pad.ctypes.data, offsets.ctypes.data, n, None if hash_only else out.ctypes.data,
                                      idx.ctypes.data if want_aux else None, strand.ctypes.data if want_aux else None,
                                      hs.ctypes.data if want_hash else None,
                                      slice_dw, n_waves, ctypes.byref(ndef), flags, ctypes.byref(nfast), ctypes.byref(nfused), int(staged), ctypes.byref(nresc), int(bool(alpha)) | (0 if solo else 2) | (4 if mixed else 0))

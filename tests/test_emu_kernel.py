@@ -664,3 +664,23 @@ def test_mixed_kernel_minimal_key_inside_a_reverse_complement_palindrome():
         a, b = int(offs[i]), int(offs[i + 1])
         assert out[a:b].tobytes() == want[i], (i, len(s))
     assert emu.last_rescued_count >= 28
+
+
+@pytest.mark.parametrize("staged,alpha", [(1, False), (1, True), (0, False), (0, True), (10, False)])
+def test_hash_only_batches_hash_a_view_of_the_input(staged, alpha):
+    """`uniq` without --canonicalize (src/uniq.rs:45,55-60) wants the XXH3 of the canonical form and no bytes: records whose
+    hash is not fused into the register routine (<= 240 symbols, N / gap records, everything the LDS tiers take) leave strand +
+    rotation, and the xxh3 pass hashes that VIEW of the input -- no canonical bytes are written, no scratch is needed (the
+    round-2 path sized one from the device's last offset, with a host synchronisation)."""
+    seqs = seqsets.random_mixed(7001, 40, 48, 1008) + seqsets.random_mixed(7002, 30, 1, 260) + seqsets.random_mixed(7003, 12, 1009, 2500) + \
+        seqsets.random_mixed(7004, 20, 30, 900, b"ACGTN") + seqsets.random_mixed(7005, 8, 10, 400, b"-ACGNT") + \
+        seqsets.random_mixed(7006, 6, 1, 300, bytes(range(0x21, 0x7F))) + seqsets.adversarial()[:60] + [b"", b"ACGTRYKMacgtn" * 30]
+    rng = np.random.default_rng(7007)
+    seqs = [seqs[i] for i in rng.permutation(len(seqs))]
+    data, offs = seqsets.pack(seqs)
+    out, _, _, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=True, want_aux=False, staged=staged, slice_dw=4096, n_waves=8,
+                                                        alpha=alpha, hash_only=True)
+    assert status == 0 and ndef == 0
+    assert (out == 0x3F).all()                                            # nothing was written as bytes
+    for i, s in enumerate(seqs):
+        assert int(h[i]) == O.xxh3_64(seqsets.expected(O, s)[0]), (i, len(s), s[:60])

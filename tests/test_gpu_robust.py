@@ -75,3 +75,40 @@ def test_set_stream_orders_the_new_stream_behind_the_old(O):
         assert np.array_equal(fs.astype(np.uint64), O.uniq_first_seen(h.astype(np.uint64)))
     setup.close()
     ctx.close()
+
+
+def test_hash_only_device_batches_enqueue_without_a_look_at_the_device(O):
+    """circkit_canonicalize_batch_device with d_out_xxh3 and WITHOUT d_out_bytes (`uniq` without --canonicalize,
+    src/uniq.rs:45,55-60): two different batches enqueued back to back on the ctx stream, nothing waited for in between --
+    the call neither synchronises nor allocates from a device-side size (it used to copy offsets[n] back to
+    size a scratch for the canonical bytes).  Records whose hash is not fused (<= 240 symbols, N / gap records, long ones)
+    are hashed through their view of the input.  Hashes against the oracle."""
+    import torch
+    import circkit_amd
+    from tests import seqsets
+    dev = torch.device("cuda", 0)
+    ctx = circkit_amd.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    batches = []
+    for seed in (1, 2):
+        seqs = seqsets.random_mixed(100 * seed, 3000, 900, 1008) + seqsets.random_mixed(100 * seed + 1, 400, 1, 260) + \
+            seqsets.random_mixed(100 * seed + 2, 300, 48, 1000, b"ACGTN") + seqsets.random_mixed(100 * seed + 3, 60, 1009, 30000) + \
+            seqsets.random_mixed(100 * seed + 4, 40, 10, 500, b"-ACGNT") + seqsets.random_mixed(100 * seed + 5, 20, 1, 300, bytes(range(0x21, 0x7F))) + \
+            [b"", b"ACGTRYKMacgtn" * 40, seqsets.random_mixed(100 * seed + 6, 1, 120_000, 120_000)[0]]
+        rng = np.random.default_rng(seed)
+        seqs = [seqs[i] for i in rng.permutation(len(seqs))]
+        data, offs = seqsets.pack(seqs)
+        d_bytes = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).to(dev)
+        d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        d_hash = torch.zeros(len(seqs), dtype=torch.int64, device=dev)
+        batches.append((data, offs, d_bytes, d_off, d_hash, len(seqs)))
+    torch.cuda.synchronize()
+    for _, _, d_bytes, d_off, d_hash, n in batches:                       # back to back
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_xxh3=d_hash)
+    assert ctx.batch_status() == 0
+    for data, offs, _, _, d_hash, n in batches:
+        _, exp_h = O.canonicalize_batch(data, offs, False, True, threads=8)
+        got = d_hash.cpu().numpy().astype(np.uint64)
+        bad = np.nonzero(got != exp_h)[0]
+        assert len(bad) == 0, (len(bad), bad[:5], [int(offs[i + 1] - offs[i]) for i in bad[:5]])
+    ctx.close()
