@@ -204,6 +204,79 @@ CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint3
     return Q;
 }
 
+// N build, the rare case (about one record in fifty at 1 % N): the packed minimal key's window holds an N and other
+// rotations share the symbols in front of it, so the packed order no longer decides.  Every rotation that does NOT share
+// them is above the winner in the true order too (canon_record_mode2n's argument), so the true minimum is among the sharers:
+// the rotations of either strand whose packed key is <= thr.  They are collected (one more pass over the words, a candidate
+// list of LEAN_CAND_MAX in LDS) and compared EXACTLY on their first 32 symbols, ranked A 0, C 2, G 4, N 5, T 6 -- packed
+// symbol x 2, or 5 where the N list marks the position.  Returns rotation | strand << 31 (record position of the forward
+// window behind the key), or ~0: too many sharers, or two of them equal on 32 symbols -- stage A's.
+// Before this, such a record cost stage A a 2-bit attempt, then the 4-bit mode on one wave behind everything else: 0.38 ms
+// of config 4's 2.4 ms step with 1 % N, for 1 % of its bytes.
+constexpr uint32_t LEAN_CAND_MAX = 16, LEAN_CAND_DW = LEAN_CAND_MAX + 2;        // + counter, + the candidate's N mask
+CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom& g, const uint16_t* nl, uint32_t n_n, uint32_t thr, uint32_t* cand)
+{
+    const uint32_t lane = lane_id(), n = g.n;
+    uint32_t* count = cand + LEAN_CAND_MAX;
+    uint32_t* nmask = cand + LEAN_CAND_MAX + 1;
+    if (lane == 0) *count = 0;
+    wave_sync();
+    // forward windows: LDS indices a16 .. T - 1.  Reverse keys: the loop yields the forward windows at 16 w - b, i.e. indices
+    // -15 .. 16 (nW - 1); n consecutive ones of them, (16 (nW - 1) - n, 16 (nW - 1)], are every rotation once
+    const int32_t r_hi = (int32_t)(16 * (g.nW - 1)), r_lo = r_hi - (int32_t)n;
+    for (uint32_t w = lane; w < g.nW; w += 64) {
+        const uint32_t cur = E[w], nxt = E[w + 1], R = rc_word<2>(cur), Rp = rc_word<2>(E[(int32_t)w - 1]);
+        const bool hit_f = word_min_key<2>(cur, nxt) <= thr, hit_r = word_min_key<2>(R, Rp) <= thr;
+        if (hit_f || hit_r) {
+#pragma nounroll
+            for (uint32_t b = 0; b < 16; ++b) {
+                const uint32_t sf = 16 * w + b;
+                const int32_t sr = (int32_t)(16 * w) - (int32_t)b;
+                if (hit_f && funnel(cur, nxt, 2 * b) <= thr && sf >= g.a16 && sf < g.T) {
+                    const uint32_t k = lds_atomic_inc(count);
+                    if (k < LEAN_CAND_MAX) cand[k] = sf - g.a16;
+                }
+                if (hit_r && funnel(R, Rp, 2 * b) <= thr && sr > r_lo && sr <= r_hi) {
+                    const int32_t q0 = sr - (int32_t)g.a16, q = q0 < 0 ? q0 + (int32_t)n : q0;
+                    const uint32_t k = lds_atomic_inc(count);
+                    if (k < LEAN_CAND_MAX) cand[k] = (uint32_t)q | 0x80000000u;
+                }
+            }
+        }
+    }
+    wave_sync();
+    const uint32_t c = *count;
+    if (c == 0 || c > LEAN_CAND_MAX) return ~0u;
+    uint32_t best = ~0u, best_rank = 0;
+    for (uint32_t k = 0; k < c; ++k) {
+        const uint32_t v = cand[k], q = v & 0x7FFFFFFFu;
+        const bool f = (v >> 31) == 0;
+        // which of the rotation's first 32 symbols are N: symbol i is forward position q + i, or (reverse strand) q + 15 - i
+        if (lane == 0) *nmask = 0;
+        wave_sync();
+        for (uint32_t e = lane; e < n_n; e += 64) {
+            const int32_t d0 = f ? (int32_t)nl[e] - (int32_t)q : (int32_t)q + 15 - (int32_t)nl[e];
+            const int32_t d = d0 < 0 ? d0 + (int32_t)n : (d0 >= (int32_t)n ? d0 - (int32_t)n : d0);
+            if (d < 32) lds_atomic_or(nmask, 1u << d);
+        }
+        wave_sync();
+        const uint32_t nm = *nmask;
+        wave_sync();                                        // (everybody has it before lane 0 clears the word for the next candidate)
+        // the symbol itself: two 16-symbol windows (the second one 16 further on the strand that is being read)
+        const uint32_t q2 = f ? (q + 16 >= n ? q + 16 - n : q + 16) : (q >= 16 ? q - 16 : q + n - 16);
+        uint32_t x0 = lean_window(E, (int32_t)(q + g.a16)), x1 = lean_window(E, (int32_t)(q2 + g.a16));
+        if (!f) { x0 = rc_word<2>(x0); x1 = rc_word<2>(x1); }
+        const uint32_t sym = ((lane & 16) ? x1 : x0) >> (30 - 2 * (lane & 15)) & 3u;
+        const uint32_t rank = lane < 32 ? (((nm >> lane) & 1u) ? 5u : 2u * sym) : 0u;
+        if (best == ~0u) { best = v; best_rank = rank; continue; }
+        const uint64_t diff = ballot(rank != best_rank);
+        if (diff == 0) return ~0u;
+        const uint32_t l = (uint32_t)ffs64(diff);
+        if (readlane(rank, l) < readlane(best_rank, l)) { best = v; best_rank = rank; }
+    }
+    return best;
+}
+
 // One record of more than FAST_MAX_N symbols in the wave's slice.  0: done; 1: not this routine's alphabet (stage A is told);
 // 2: pure as far as seen, but a tie / equal strands / no room (stage A's general routine).
 #ifndef CK_LEAN_MIN_PREFIX
@@ -227,11 +300,12 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         g.a16 = 0; g.T = n; g.nW = (n + 15) >> 4;
     }
     const uint32_t strand_dw = lean_strand_dw(n);
-    if (strand_dw > a.slice_dw || (NM && n > 0xFFFFu)) return 2;
+    if (strand_dw + (NM ? LEAN_CAND_DW : 0) > a.slice_dw || (NM && n > 0xFFFFu)) return 2;
     uint32_t* E = slice + 1;
     uint32_t* nl_count = E + g.nW + 1;                                    // (the strand's spare word)
     uint16_t* nl = reinterpret_cast<uint16_t*>(slice + strand_dw);
-    const uint32_t nl_cap = 2 * (a.slice_dw - strand_dw);
+    // (NM: the slice's last LEAN_CAND_DW dwords are lean_resolve_n's candidate list)
+    const uint32_t nl_cap = NM && a.slice_dw > strand_dw + LEAN_CAND_DW ? 2 * (a.slice_dw - strand_dw - LEAN_CAND_DW) : 0;
     if constexpr (NM) {
         if (lane == 0) *nl_count = 0;
         wave_sync();
@@ -271,7 +345,7 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
     const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bties = fwd ? bF.ties : bC.ties, bword2 = fwd ? bF.word2 : bC.word2;
     const uint64_t owners = ballot(bties != 0 && bkey == M);
     // rotation index on the winning strand; the forward window behind reverse position p starts at n - 16 - p
-    const uint32_t idx = fwd ? (uint32_t)Q : (uint32_t)((int32_t)n - 16 - Q < 0 ? 2 * (int32_t)n - 16 - Q : (int32_t)n - 16 - Q);
+    uint32_t idx = fwd ? (uint32_t)Q : (uint32_t)((int32_t)n - 16 - Q < 0 ? 2 * (int32_t)n - 16 - Q : (int32_t)n - 16 - Q);
     if constexpr (NM) {
         // An N inside the winning window -- the forward positions Q .. Q + 15 on either strand -- is where the packed key
         // differs from the true one: canon_record_mode2n's prefix rule (canon_core.h).  Offset of the first N in the
@@ -284,7 +358,7 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         first = wave_min_u32(first);
         if (first < 16) {
             const uint32_t plen = fwd ? first + 1 : first;
-            if (plen < CK_LEAN_MIN_PREFIX) return 1;
+            if (plen == 0) return 1;
             // "No other rotation of either strand shares the winner's first plen packed symbols" = no other key is <= thr (M
             // is the smallest of all).  The scan has kept every lane's smallest word minimum on both strands and, on top, the
             // smallest among its OTHER words: nothing but the owner words may reach down to thr, and inside them only the
@@ -292,11 +366,19 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
             const uint32_t sh = 32 - 2 * plen, thr = M | (sh ? 0xFFFFFFFFu >> (32 - sh) : 0u);
             const bool mine = ((owners >> lane) & 1) != 0;
             const uint32_t lowest_other = fwd ? bC.key : bF.key, lowest_w = mine ? (fwd ? bF.second : bC.second) : bkey;
-            if (ballot(lowest_other <= thr || lowest_w <= thr) != 0) return 1;
-            for (uint64_t h2 = owners; h2; h2 &= h2 - 1) {
+            bool alone = plen >= CK_LEAN_MIN_PREFIX && ballot(lowest_other <= thr || lowest_w <= thr) == 0;
+            for (uint64_t h2 = owners; alone && h2; h2 &= h2 - 1) {
                 const uint32_t l = (uint32_t)ffs64(h2), j = readlane(bword, l), j2 = readlane(bword2, l);
-                if (popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) return 1;
-                if (readlane(bties, l) == 2 && popc64(ballot(lane < 16 && lean_key_at(E, j2, lane & 15, fwd) <= thr)) != 1) return 1;
+                if (popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) alone = false;
+                if (readlane(bties, l) == 2 && popc64(ballot(lane < 16 && lean_key_at(E, j2, lane & 15, fwd) <= thr)) != 1) alone = false;
+            }
+            if (!alone) {
+                // other rotations share those symbols: the true minimum is one of the sharers (lean_resolve_n)
+                const uint32_t v = lean_resolve_n(E, g, nl, n_n, thr, slice + a.slice_dw - LEAN_CAND_DW);
+                if (v == ~0u) return 1;
+                fwd = (v >> 31) == 0;
+                Q = (int32_t)(v & 0x7FFFFFFFu);
+                idx = fwd ? (uint32_t)Q : (uint32_t)((int32_t)n - 16 - Q < 0 ? 2 * (int32_t)n - 16 - Q : (int32_t)n - 16 - Q);
             }
         }
     }

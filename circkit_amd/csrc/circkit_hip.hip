@@ -399,7 +399,7 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
 #define CK_MIXED_NM_VGPR 36
 #endif
 #ifndef CK_MIXED_N_SLICE
-#define CK_MIXED_N_SLICE 1368     // dwords per wave of canon_mixed_n_kernel: the most that still leaves seven workgroups per CU
+#define CK_MIXED_N_SLICE 1596     // dwords per wave of canon_mixed_n_kernel: six workgroups per CU (measured: 1368 = seven workgroups 2.38 ms, 1596 2.33 -- the N list of a 20 kb record needs the room)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(36))) void canon_mixed_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode,
                                                                                              uint32_t* mode_out, uint32_t* tiers_busy)
@@ -1096,8 +1096,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             if (host_mode && ((host_mode & MODE_ALPHA) != 0) != (nm != 0)) continue;
             const bool expected = host_mode ? true : ((seen & 3) == 3 && ((seen & MODE_ALPHA) != 0) == (nm != 0));
             const unsigned grid = expected ? nseg : walking;
-            // the N build keeps a list of the record's N positions behind the strand: a slightly bigger slice (still seven
-            // workgroups = 28 waves per CU), so that a 20 kb record of config 4 has room for the ~200 it holds at 1 %
+            // the N build keeps a list of the record's N positions (and lean_resolve_n's candidates) behind the strand: a bigger
+            // slice (six workgroups = 24 waves per CU), so that a 20 kb record of config 4 has room for the ~200 N it holds at 1 %
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
             const size_t shmem = (4 * a.slice_dw + TIER_EXTRA_DW) * 4;
             if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
@@ -1110,6 +1110,19 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         std::vector<uint32_t> cnt(nseg);
         (void)hipMemcpy(cnt.data(), c->d_seg_counts + c->seg_alloc, nseg * 4, hipMemcpyDeviceToHost);
         uint64_t total = 0; unsigned shown = 0;
+        if (getenv("CK_DUMP_HIST")) {       // length histogram of the deferred records (powers of two), flagged / not
+            std::vector<uint32_t> ents((size_t)nseg * seg_cap);
+            (void)hipMemcpy(ents.data(), c->d_lists[1], ents.size() * 4, hipMemcpyDeviceToHost);
+            std::vector<uint64_t> offs(n + 1);
+            (void)hipMemcpy(offs.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost);
+            uint64_t hist[2][32] = {}, bytes[2] = {};
+            for (unsigned sg = 0; sg < nseg; ++sg)
+                for (uint32_t k = 0; k < cnt[sg]; ++k) {
+                    const uint32_t e = ents[(size_t)sg * seg_cap + k]; const uint64_t len = offs[(e & ck::ENTRY_REC) + 1] - offs[e & ck::ENTRY_REC];
+                    hist[e >> 31][63 - __builtin_clzll(len | 1)]++; bytes[e >> 31] += len;
+                }
+            for (int f = 0; f < 2; ++f) { fprintf(stderr, "[dump] flag %d (%llu bytes):", f, (unsigned long long)bytes[f]); for (int b = 0; b < 32; ++b) if (hist[f][b]) fprintf(stderr, " 2^%d:%llu", b, (unsigned long long)hist[f][b]); fprintf(stderr, "\n"); }
+        }
         for (unsigned sg = 0; sg < nseg; ++sg) {
             total += cnt[sg];
             for (uint32_t k = 0; k < cnt[sg] && shown < 12; ++k, ++shown) {

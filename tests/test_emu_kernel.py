@@ -684,3 +684,34 @@ def test_hash_only_batches_hash_a_view_of_the_input(staged, alpha):
     assert (out == 0x3F).all()                                            # nothing was written as bytes
     for i, s in enumerate(seqs):
         assert int(h[i]) == O.xxh3_64(seqsets.expected(O, s)[0]), (i, len(s), s[:60])
+
+
+def test_mixed_kernel_n_inside_the_minimal_window_is_resolved_among_the_sharers():
+    """N build: an N inside the packed minimal key's window, other rotations sharing the symbols in front of it -- the
+    true minimum is one of the sharers, found by lean_resolve_n (exact ranks A C G N T over 32 symbols) instead of a trip
+    through stage A's 4-bit mode.  Planted A-runs with an N at every offset, a second shorter A-run as the sharer, both
+    strands, plus N-rich random and two-letter records."""
+    import random
+    rng = random.Random(2025)
+    seqs = [_sprinkle(rng, seqsets.rand_seq(rng, rng.randint(1009, 2600)), rng.choice([0.01, 0.03, 0.08])) for _ in range(40)]
+    seqs += [_sprinkle(rng, seqsets.rand_seq(rng, rng.randint(1009, 2200), b"AC"), 0.02) for _ in range(6)]
+    for k in range(40):
+        n = rng.randint(1100, 2400)
+        s = bytearray(seqsets.rand_seq(rng, n, b"CGT"))
+        pos, pos2 = rng.randrange(n), rng.randrange(n)
+        for i in range(rng.randint(8, 16)):
+            s[(pos + i) % n] = ord("A")
+        s[(pos + k % 13) % n] = ord("N")
+        for i in range(rng.randint(5, 10)):
+            s[(pos2 + i) % n] = ord("A")
+        s = bytes(s)
+        seqs.append(s if k % 2 else seqsets.revcomp_acgt(s.replace(b"N", b"X")).replace(b"X", b"N"))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    out, _, _, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=False, staged=0, slice_dw=1368, n_waves=8,
+                                                        alpha=True, mixed=True, base_shift=3)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i], (i, len(s))
+    assert emu.last_rescued_count >= len(seqs) - 8
