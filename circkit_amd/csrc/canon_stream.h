@@ -80,6 +80,28 @@ CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, u
     return grp;
 }
 
+#ifdef CK_DEBUG_POISON
+// Test build (tests/poison.py, never the product library): a guard for the hand-counted vmcnt protocol below.  Right before
+// a ring image's DMA is re-issued every wave overwrites its slots of that image with a pattern no payload byte can form
+// (the writes are waited for, so the DMA data lands on top of them); a record whose aligned chunk still reads the pattern
+// when it is packed was consumed before its DMA had landed -- counted in status[9] (d_counters[12]), read back by
+// circkit_debug_poison_count.  On the CPU emulator the DMA is a synchronous memcpy, so only the GPU can tell.
+constexpr uint32_t CK_POISON = 0xFEFEFEFEu;
+template <class C>
+CK_DEV void stream_poison(uint32_t* buf)
+{
+    const uint32_t w = wave_in_block(), t = lane_id();
+#pragma unroll
+    for (uint32_t i = 0; i < (uint32_t)C::DPW; ++i) lds_store16(buf + stream_slot<C>(w, i) * 256 + 4 * t, u32x4{ CK_POISON, CK_POISON, CK_POISON, CK_POISON });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+CK_DEV void stream_poison_check(const CanonArgs& a, u32x4 v, uint64_t lanes)
+{
+    const uint64_t hit = ballot(v.x == CK_POISON || v.y == CK_POISON || v.z == CK_POISON || v.w == CK_POISON) & lanes;
+    if (hit != 0 && lane_id() == 0) atomic_add_u32(a.status + 9, 1u);
+}
+#endif
+
 // loop of one wave of a workgroup; every wave of the workgroup runs the same number of iterations (barriers inside).
 // GH: XXH3 is finished per record group by one wave (canon_fast.h, group_hash_*); gh = its LDS area (gh_lds_dw<GROUP>()
 // dwords, constants initialised by group_hash_init).
@@ -119,6 +141,9 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         const uint32_t g = block + d * nblocks, gg = g < n_staged ? g : 0;
         uint64_t s, e;
         sload_2u64(a.offsets + (uint64_t)gg * C::GROUP, a.offsets + (uint64_t)gg * C::GROUP + C::GROUP, s, e);
+#ifdef CK_DEBUG_POISON
+        stream_poison<C>(ring + d * C::BUF_DW);
+#endif
         q[d] = stream_issue<C>(a, g < n_staged, s, e, ring + d * C::BUF_DW, c16);
     }
     vmem_wait<(D - 1) * C::DPW>();                    // the first group's DMAs; the later ones may still fly
@@ -131,6 +156,9 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         uint64_t s, e, o0, o1, o2;
         sload_group<(int)C::GROUP>(a.offsets + (uint64_t)gfc * C::GROUP, a.offsets + ra, s, e, o0, o1, o2);
         const uint32_t bf = bi ? bi - 1 : C::NBUF - 1;                     // the buffer freed by the previous iteration
+#ifdef CK_DEBUG_POISON
+        stream_poison<C>(ring + bf * C::BUF_DW);
+#endif
         const StreamGroup fut = stream_issue<C>(a, gf < n_staged, s, e, ring + bf * C::BUF_DW, c16);
         const uint32_t* img = ring + bi * C::BUF_DW;
         uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + w) * GH_STRIDE_DW : nullptr;
@@ -149,6 +177,10 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 const uint32_t P0 = fast_pack(lds_load16(cp), m0), P1 = fast_pack(lds_load16(cp + 4), m1);
                 const uint64_t bad0 = ballot(m0 != 0) & (~0ull >> (64 - ((nch + 1) >> 1)));       // chunk 2t   < nch
                 const uint64_t bad1 = ballot(m1 != 0) & ((nch >> 1) >= 64 ? ~0ull : (1ull << (nch >> 1)) - 1);   // chunk 2t+1 < nch
+#ifdef CK_DEBUG_POISON
+                stream_poison_check(a, lds_load16(cp), ~0ull >> (64 - ((nch + 1) >> 1)));
+                stream_poison_check(a, lds_load16(cp + 4), (nch >> 1) >= 64 ? ~0ull : (1ull << (nch >> 1)) - 1);
+#endif
                 const uint32_t sh2 = 32 - 2 * a16;
                 done = fast_canon2<HASH, AUX>(a, lut, hc, rec, off, n, lshr64(P0, P1, sh2), lshr64(P1, wave_shl1(P0), sh2), (bad0 | bad1) != 0);
             } else if (q[0].ok && fast_eligible(n)) {
@@ -157,6 +189,9 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;
                 const u32x4 v = lds_load16(img + 4 * ((rel >> 4) + t));
                 const uint64_t chunks = ~0ull >> (64 - nch);                            // 3 <= nch <= 64
+#ifdef CK_DEBUG_POISON
+                stream_poison_check(a, v, chunks);
+#endif
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
                 uint64_t bad;                       // lanes with a byte the 2-bit routines cannot take
@@ -208,9 +243,13 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         // the DMAs of the D-1 groups issued since (DPW each), and the stores of this and the D-1 previous iterations
         // (>= RPW each: every record stores its bytes, hash or index, or its deferral).  While the next group is still
         // one of the prologue's (it + 1 < D) there are fewer stores: only this iteration's are counted on.
+#ifdef CK_DEBUG_POISON_BREAK
+        vmem_wait<63>();                                  // negative control of the poison guard: no wait at all -- the count must NOT stay zero
+#else
         if (!stores) vmem_wait<(D - 1) * C::DPW>();
         else if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + C::RPW>();
         else vmem_wait<(D - 1) * C::DPW + D * C::RPW>();
+#endif
         block_barrier();
 #pragma unroll
         for (int d = 0; d + 1 < D; ++d) q[d] = q[d + 1];

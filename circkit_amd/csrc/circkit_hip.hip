@@ -1790,6 +1790,19 @@ int circkit_bench_copy_device(circkit_ctx* c, const void* d_src, void* d_dst, ui
     return CIRCKIT_OK;
 }
 
+#ifdef CK_DEBUG_POISON
+// Test build only (tests/poison.py; not in include/circkit.h): records of all batches since ctx creation whose staged chunk was
+// read before its DMA had landed (canon_stream.h stream_poison).  Synchronizes.
+int circkit_debug_poison_count(circkit_ctx* c, uint32_t* n)
+{
+    if (!c || !n) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    CK_HIP(c, hipMemcpy(n, c->d_counters + 12, 4, hipMemcpyDeviceToHost));
+    return CIRCKIT_OK;
+}
+#endif
+
 // needletail 0.5.1 sequence::normalize(seq, false) -- host logic of the CSR packer.
 size_t circkit_normalize(const uint8_t* s, size_t n, uint8_t* out, int* changed)
 {
