@@ -719,40 +719,48 @@ __global__ __launch_bounds__(256) void uniq_partition_count_kernel(const uint64_
     if (threadIdx.x < world && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 // pass 2: rows[(pos)] = {hash, base + i} with the rows of one owner together (owners in rank order, any order inside),
-// slot[i] = pos.  Each workgroup takes chunks of 256 * 16 keys: a histogram of the chunk, one global atomic per owner to
-// reserve its rows, then every key its place.
+// slot[i] = pos.  Each workgroup takes chunks of 256 * PER keys: a histogram of the chunk in LDS (the LDS atomic's return value
+// is the key's rank inside its owner's share of the chunk), one global atomic per owner to reserve the chunk's rows, then every
+// key its place.  PER = 4 with the keys RE-READ in the second phase (they are in the vector cache) instead of 16 with owner and
+// rank of every key kept in registers: 131 VGPRs / 3 waves per SIMD -> under 40 / 8; the owners' base
+// offsets are a prefix sum of the 64 counts done once per workgroup, not a loop per chunk.
 __global__ __launch_bounds__(256) void uniq_partition_scatter_kernel(const uint64_t* __restrict__ hash, uint64_t n, uint64_t base, uint32_t world,
                                                                      const unsigned long long* __restrict__ counts, unsigned long long* cursor,
                                                                      uint64_t* rows, uint32_t* slot)
 {
     __shared__ uint32_t hist[UNIQ_MAX_WORLD];
-    __shared__ unsigned long long start[UNIQ_MAX_WORLD];
-    constexpr uint32_t PER = 16;
+    __shared__ unsigned long long first[UNIQ_MAX_WORLD], start[UNIQ_MAX_WORLD];
+    constexpr uint32_t PER = 4;
     const uint64_t chunk = 256ull * PER;
+    if (threadIdx.x < UNIQ_MAX_WORLD) {                       // (one wave) exclusive prefix sum of the owners' totals
+        unsigned long long v = threadIdx.x < world ? counts[threadIdx.x] : 0ull, incl = v;
+        for (uint32_t d = 1; d < UNIQ_MAX_WORLD; d <<= 1) {
+            const uint32_t lo = ck::shfl((uint32_t)incl, threadIdx.x - d), hi = ck::shfl((uint32_t)(incl >> 32), threadIdx.x - d);
+            if (threadIdx.x >= d) incl += ((unsigned long long)hi << 32) | lo;
+        }
+        first[threadIdx.x] = incl - v;
+    }
     for (uint64_t c0 = (uint64_t)blockIdx.x * chunk; c0 < n; c0 += (uint64_t)gridDim.x * chunk) {
         if (threadIdx.x < UNIQ_MAX_WORLD) hist[threadIdx.x] = 0;
         __syncthreads();
-        uint32_t own[PER], rank[PER];
+        uint32_t rank[PER];
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint64_t i = c0 + k * 256 + threadIdx.x;
-            own[k] = i < n ? uniq_owner(hash[i], world) : 0xFFFFFFFFu;
-            rank[k] = i < n ? atomicAdd(&hist[own[k]], 1u) : 0u;
+            rank[k] = i < n ? atomicAdd(&hist[uniq_owner(hash[i], world)], 1u) : 0u;
         }
         __syncthreads();
-        if (threadIdx.x < world) {
-            unsigned long long first = 0;
-            for (uint32_t w = 0; w < threadIdx.x; ++w) first += counts[w];              // (world is small)
-            start[threadIdx.x] = first + (hist[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)hist[threadIdx.x]) : 0ull);
-        }
+        if (threadIdx.x < world)
+            start[threadIdx.x] = first[threadIdx.x] + (hist[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)hist[threadIdx.x]) : 0ull);
         __syncthreads();
 #pragma unroll
         for (uint32_t k = 0; k < PER; ++k) {
             const uint64_t i = c0 + k * 256 + threadIdx.x;
             if (i < n) {
-                const uint64_t pos = start[own[k]] + rank[k];
+                const uint64_t h = hash[i];
+                const uint64_t pos = start[uniq_owner(h, world)] + rank[k];
                 typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<v2*>(rows + 2 * pos) = v2{ hash[i], base + i };
+                *reinterpret_cast<v2*>(rows + 2 * pos) = v2{ h, base + i };
                 slot[i] = (uint32_t)pos;
             }
         }
@@ -1679,7 +1687,7 @@ int circkit_uniq_partition_device(circkit_ctx* c, const uint64_t* d_hash, uint64
     CK_HIP(c, hipMemsetAsync(c->d_hash, 0, UNIQ_MAX_WORLD * sizeof(uint64_t), c->stream));
     if (n == 0) return CIRCKIT_OK;
     hipLaunchKernelGGL(uniq_partition_count_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, world, (unsigned long long*)d_counts);
-    hipLaunchKernelGGL(uniq_partition_scatter_kernel, dim3(N_CU * 4), dim3(256), 0, c->stream, d_hash, n, base_index, world,
+    hipLaunchKernelGGL(uniq_partition_scatter_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, d_hash, n, base_index, world,
                        (const unsigned long long*)d_counts, (unsigned long long*)c->d_hash, d_rows, d_slot);
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
