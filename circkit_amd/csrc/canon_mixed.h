@@ -111,9 +111,12 @@ CK_DEV void lean_extend(const LeanGeom& g, uint32_t* E)
     wave_sync();
 }
 
-// per-lane running minimum over the lane's words: key, the word that holds it first, how many of the lane's words hold it;
-// SECOND (the N build's prefix rule): the smallest minimum among the lane's OTHER words
-struct LeanBest { uint32_t key = ~0u, word = 0, ties = 0, second = ~0u, word2 = 0; };     // word2: the second word of the lane that holds the minimum
+// per-lane running minimum over the lane's words (lane l holds words l, l + 64, ...): key, the word that holds it first, how
+// many of the lane's words hold it; SECOND (the N build's prefix rule): the smallest minimum among the lane's OTHER words.
+// (Two words of one lane with the minimum are mostly ONE position seen twice -- in word 0 or 1 and, as its periodic twin, in
+// the last words, which share a lane when the record is a little longer than a multiple of 1024 symbols; lean_locate then
+// walks the lane's words again.)
+struct LeanBest { uint32_t key = ~0u, word, ties = 0, second = ~0u; };
 template <bool SECOND>
 CK_DEV void lean_update(LeanBest& b, uint32_t m, uint32_t w)
 {
@@ -121,11 +124,10 @@ CK_DEV void lean_update(LeanBest& b, uint32_t m, uint32_t w)
         const uint32_t hi = m > b.key ? m : b.key;
         b.second = hi < b.second ? hi : b.second;
     }
-    const bool lt = m < b.key || b.ties == 0, eq = !lt && m == b.key;
-    // (two words of one lane with the minimum: mostly ONE position seen twice -- in word 0 or 1 and, as its periodic twin, in
-    // the last words, which share a lane when the record is a little longer than a multiple of 1024 symbols)
-    b.word2 = eq ? w : b.word2;
-    b.ties = lt ? 1u : b.ties + (eq ? 1u : 0u);
+    // (key starts at ~0 and word at the lane's first word: a first minimum of ~0 counts as a tie with the initial state, which
+    // names the right word already)
+    const bool lt = m < b.key;
+    b.ties = lt ? 1u : b.ties + (m == b.key ? 1u : 0u);
     b.word = lt ? w : b.word;
     b.key = lt ? m : b.key;
 }
@@ -176,29 +178,30 @@ CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint3
 {
     const uint32_t lane = lane_id();
     uint64_t hm = ballot(b.ties != 0 && b.key == M);
-    if (ballot(b.ties > 2 && b.key == M) != 0 || popc64(hm) > 8) return -1;
+    if (ballot(b.ties > 4 && b.key == M) != 0 || popc64(hm) > 8) return -1;
     int32_t Q = -1;
     uint32_t rivals = 0;
-    uint32_t second_round = 0;                      // (the owner lane's second word)
     while (hm) {
         const uint32_t l = (uint32_t)ffs64(hm);
-        const uint32_t j = second_round ? readlane(b.word2, l) : readlane(b.word, l);
-        if (!second_round && readlane(b.ties, l) == 2) second_round = 1;
-        else { second_round = 0; hm &= hm - 1; }
-        const uint32_t key = lean_key_at(E, j, lane & 15, fwd);
-        uint64_t pm = ballot(lane < 16 && key == M);
-        if (NM && popc64(pm) != 1) return -1;
-        while (pm) {
-            const int32_t bit = ffs64(pm);
-            pm &= pm - 1;
-            int32_t q = (fwd ? (int32_t)(16 * j) + bit : (int32_t)(16 * j) - bit) - (int32_t)g.a16;     // record position of the forward window
-            q = q < 0 ? q + (int32_t)g.n : (q >= (int32_t)g.n ? q - (int32_t)g.n : q);
-            if (Q < 0) { Q = q; continue; }
-            if (q == Q) continue;
-            if (NM || ++rivals > 8) return -1;
-            const int c = lean_cmp_rot(E, g, fwd, (uint32_t)q, fwd, (uint32_t)Q);
-            if (c == 0) return -1;
-            if (c < 0) Q = q;
+        hm &= hm - 1;
+        // the owner lane's word with the minimum -- or, when two of its words hold it, every word of the lane from that one on
+        const uint32_t j0 = readlane(b.word, l), j1 = readlane(b.ties, l) == 1 ? j0 + 1 : g.nW;
+        for (uint32_t j = j0; j < j1; j += 64) {
+            const uint32_t key = lean_key_at(E, j, lane & 15, fwd);
+            uint64_t pm = ballot(lane < 16 && key == M);
+            if (NM && j == j0 && popc64(pm) != 1) return -1;
+            while (pm) {
+                const int32_t bit = ffs64(pm);
+                pm &= pm - 1;
+                int32_t q = (fwd ? (int32_t)(16 * j) + bit : (int32_t)(16 * j) - bit) - (int32_t)g.a16;     // record position of the forward window
+                q = q < 0 ? q + (int32_t)g.n : (q >= (int32_t)g.n ? q - (int32_t)g.n : q);
+                if (Q < 0) { Q = q; continue; }
+                if (q == Q) continue;
+                if (NM || ++rivals > 8) return -1;
+                const int c = lean_cmp_rot(E, g, fwd, (uint32_t)q, fwd, (uint32_t)Q);
+                if (c == 0) return -1;
+                if (c < 0) Q = q;
+            }
         }
     }
     return Q;
@@ -320,6 +323,7 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
     if (NM && n_n > nl_cap) return 1;                                     // more N than the list holds: stage A's bitmask mode
     // both strands' minimal keys in one pass over the words
     LeanBest bF, bC;
+    bF.word = bC.word = lane;
     for (uint32_t w = lane; w < g.nW; w += 64) {
         const uint32_t cur = E[w], nxt = E[w + 1], prv = E[(int32_t)w - 1];
         lean_update<NM>(bF, word_min_key<2>(cur, nxt), w);
@@ -342,7 +346,7 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         if (Q < 0) return 2;
     }
     const uint32_t M = fwd ? MF : MC;
-    const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bties = fwd ? bF.ties : bC.ties, bword2 = fwd ? bF.word2 : bC.word2;
+    const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bties = fwd ? bF.ties : bC.ties;
     const uint64_t owners = ballot(bties != 0 && bkey == M);
     // rotation index on the winning strand; the forward window behind reverse position p starts at n - 16 - p
     uint32_t idx = fwd ? (uint32_t)Q : (uint32_t)((int32_t)n - 16 - Q < 0 ? 2 * (int32_t)n - 16 - Q : (int32_t)n - 16 - Q);
@@ -368,9 +372,8 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
             const uint32_t lowest_other = fwd ? bC.key : bF.key, lowest_w = mine ? (fwd ? bF.second : bC.second) : bkey;
             bool alone = plen >= CK_LEAN_MIN_PREFIX && ballot(lowest_other <= thr || lowest_w <= thr) == 0;
             for (uint64_t h2 = owners; alone && h2; h2 &= h2 - 1) {
-                const uint32_t l = (uint32_t)ffs64(h2), j = readlane(bword, l), j2 = readlane(bword2, l);
-                if (popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) alone = false;
-                if (readlane(bties, l) == 2 && popc64(ballot(lane < 16 && lean_key_at(E, j2, lane & 15, fwd) <= thr)) != 1) alone = false;
+                const uint32_t l = (uint32_t)ffs64(h2), j = readlane(bword, l);
+                if (readlane(bties, l) != 1 || popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) alone = false;
             }
             if (!alone) {
                 // other rotations share those symbols: the true minimum is one of the sharers (lean_resolve_n)
@@ -384,14 +387,23 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
     }
     if (a.out_bytes) {
         uint8_t* out = a.out_bytes + off;
-        for (uint32_t w = lane; 16 * w < n; w += 64) {
-            const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16;              // the last window is pulled back to end at n
-            uint32_t p = idx + o;
-            p = p >= n ? p - n : p;
-            // LDS index of the forward window behind the 16 output symbols
-            const uint32_t s = (fwd ? p : (p + 16 <= n ? n - 16 - p : 2 * n - 16 - p)) + g.a16;
-            const uint32_t x = lean_window(E, (int32_t)s);
-            store16(out + o, fast_decode(lut, fwd ? x : rc_word<2>(x)));
+        // (two loops: the strand is the same for the whole record, and a select inside one loop computed both strands' words)
+        if (fwd) {
+            for (uint32_t w = lane; 16 * w < n; w += 64) {
+                const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16;          // the last window is pulled back to end at n
+                uint32_t p = idx + o;
+                p = p >= n ? p - n : p;
+                store16(out + o, fast_decode(lut, lean_window(E, (int32_t)(p + g.a16))));
+            }
+        } else {
+            for (uint32_t w = lane; 16 * w < n; w += 64) {
+                const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16;
+                uint32_t p = idx + o;
+                p = p >= n ? p - n : p;
+                // LDS index of the forward window behind the 16 output symbols
+                const uint32_t s = (p + 16 <= n ? n - 16 - p : 2 * n - 16 - p) + g.a16;
+                store16(out + o, fast_decode(lut, rc_word<2>(lean_window(E, (int32_t)s))));
+            }
         }
         if constexpr (NM) {
             if (n_n) {
