@@ -324,6 +324,24 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         idx = fast2_locate(fwd ? F : C, fwd ? Fn : Cn, fwd ? ballot(mF == MF) : ballot(mC == MC), fwd ? MF : MC, n, shv, uE);
         iF = idx;
         if (AUX && a.out_index && !fwd) iF = fast2_locate(F, Fn, ballot(mF == MF), MF, n, shv, uF);
+        if constexpr (!AUX && !NM) {
+            if (tie) {
+                // Equal minimal keys on the two strands -- a minimal 16-mer inside a reverse-complement palindrome of 18+, which
+                // both strands then own: ~10 records per million of random 1 kb DNA.  The two minimal rotations are compared in
+                // full right here, one 16-symbol word per lane (lib/src/canonicalize.rs:58-62: forward only if strictly smaller;
+                // equal = the record is its own reverse complement, either strand's bytes are the same).  Left to the general
+                // kernel these few records were a ~30 us pass of LDS stage A behind every batch of the headline workload.
+                bool uC;
+                const uint32_t iC = fast2_locate(C, Cn, ballot(mC == MC), MC, n, shv, uC);     // (idx = the forward strand's: fwd was MF <= MC)
+                if (!uE || !uC) return false;
+                const uint32_t x = reg_sym_word(F, idx + (valid ? 16 * t : 0), n), y = reg_sym_word(C, iC + (valid ? 16 * t : 0), n);
+                const uint64_t d = ballot(valid && x != y);
+                fwd = false;
+                if (d != 0) { const uint32_t l = (uint32_t)ffs64(d); fwd = readlane(x, l) < readlane(y, l); }
+                idx = fwd ? idx : iC;
+                tie = false;
+            }
+        }
         if (tie || !uE || !uF) return false;
     }
     const uint32_t E = fwd ? F : C;

@@ -25,7 +25,7 @@ for k in range(0, len(args), 4):
         "workload": workload,
         "kernel": kernel,
         "scope": "the workload's dominant kernel, per launch",
-        "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per launch)" % path.replace("gpurun_out/refresh/", "profiles/"),
+        "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, per launch)" % ("profiles/" + path.rsplit("/", 1)[-1]),
         "fetch_bytes": fetch, "write_bytes": write, "traffic_bytes": fetch + write,
         "correction": "FETCH_SIZE x2 (gfx950 wide-read undercount), WRITE_SIZE exact",
         "insts_valu_per_record": vals["SQ_INSTS_VALU"] / n, "insts_salu_per_record": vals["SQ_INSTS_SALU"] / n,
