@@ -1103,7 +1103,12 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         for (uint32_t nm = 0; nm < 2; ++nm) {
             if (host_mode && ((host_mode & MODE_ALPHA) != 0) != (nm != 0)) continue;
             const bool expected = host_mode ? true : ((seen & 3) == 3 && ((seen & MODE_ALPHA) != 0) == (nm != 0));
-            const unsigned grid = expected ? nseg : walking;
+#ifdef CK_MIXED_BPC
+            const unsigned full = nseg < (unsigned)N_CU * CK_MIXED_BPC ? nseg : (unsigned)N_CU * CK_MIXED_BPC;
+#else
+            const unsigned full = nseg;
+#endif
+            const unsigned grid = expected ? full : walking;
             // the N build keeps a list of the record's N positions (and lean_resolve_n's candidates) behind the strand: a bigger
             // slice (six workgroups = 24 waves per CU), so that a 20 kb record of config 4 has room for the ~200 N it holds at 1 %
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];

@@ -146,6 +146,50 @@ def test_build_selection_follows_the_batch_not_the_buffer(ctx, O):
         assert np.array_equal(d_out[:len(data)].cpu().numpy(), exp)
 
 
+def test_every_mode_and_alphabet_back_to_back_without_a_wait(O):
+    """Batches of all six (mode, alphabet) kinds -- short / 1.5 kb / mixed lengths, pure and with 1 % N -- enqueued one
+    behind the other on one stream, twice round, nothing waited for in between: every batch's kernels are chosen on the
+    device from the batch itself (the builds that do not match return at once, the grid-size hint lags a batch behind), with
+    bytes only and with bytes + XXH3.  Round 3 added the two mixed-length kernels to the set."""
+    import random
+    import torch
+    import circkit_amd
+    from tests import seqsets
+    dev = torch.device("cuda", 0)
+    ctx = circkit_amd.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = random.Random(9)
+
+    def sprinkle(s):
+        b = bytearray(s)
+        for i in range(len(b)):
+            if rng.random() < 0.01:
+                b[i] = ord("N")
+        return bytes(b)
+
+    kinds = [seqsets.random_mixed(301, 6000, 300, 1008), seqsets.random_mixed(302, 4000, 1100, 1900), seqsets.random_mixed(303, 3000, 200, 20000)]
+    kinds += [[sprinkle(s) for s in k] for k in kinds]
+    jobs = []
+    for rnd in range(2):
+        for k, seqs in enumerate(kinds):
+            data, offs = seqsets.pack(seqs)
+            d_bytes = torch.from_numpy(np.concatenate([np.zeros(k % 16, np.uint8), data])).to(dev)[k % 16:]     # every payload alignment
+            d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+            d_out = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+            d_hash = torch.zeros(len(seqs), dtype=torch.int64, device=dev) if (k + rnd) % 2 else None
+            jobs.append((data, offs, d_bytes, d_off, d_out, d_hash, len(seqs)))
+    torch.cuda.synchronize()
+    for _, _, d_bytes, d_off, d_out, d_hash, n in jobs:
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash)
+    assert ctx.batch_status() == 0
+    for j, (data, offs, _, _, d_out, d_hash, n) in enumerate(jobs):
+        exp, exp_h = O.canonicalize_batch(data, offs, True, d_hash is not None, threads=8)
+        assert np.array_equal(d_out[:len(data)].cpu().numpy(), exp), j
+        if d_hash is not None:
+            assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h), j
+    ctx.close()
+
+
 def _run(cmd, env=None, timeout=900):
     e = dict(os.environ)
     e.update(env or {})
