@@ -18,7 +18,10 @@ def build(force=False, negative_control=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "circkit.h")]
     if not force and os.path.exists(lib) and all(os.path.getmtime(d) <= os.path.getmtime(lib) for d in deps):
         return lib
-    hipcc = "/opt/rocm/bin/hipcc"
+    import sys
+    sys.path.insert(0, ROOT)
+    from circkit_amd.build import _hipcc
+    hipcc = _hipcc()
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-inline-asm", "-DCK_DEBUG_POISON"] +
                           (["-DCK_DEBUG_POISON_BREAK"] if negative_control else []) +
                           ["-o", lib, os.path.join(CSRC, "circkit_hip.hip"), os.path.join(CSRC, "fasta_host.cpp")])

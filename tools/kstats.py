@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Prints a rocprofv3 *_kernel_stats.csv compactly: name (shortened), calls, average us, share."""
-import csv, sys
+import csv, signal, sys
+signal.signal(signal.SIGPIPE, signal.SIG_DFL)        # `| head` is a normal way to read this
 for path in sys.argv[1:]:
     print("==", path)
     for r in list(csv.DictReader(open(path)))[:14]:
