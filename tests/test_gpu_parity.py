@@ -766,3 +766,18 @@ def test_randomized_n_paths(profile, count):
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+@pytest.mark.parametrize("seed", ["20", "21"])
+def test_randomized_lean_routine_ties(seed):
+    """tools/gpu_fuzz.py "leanties": records of 1..20 kb aimed at what the mixed kernel's lean routine settles itself -- a
+    minimal 16-mer owned several times, a palindromic core both strands own, the minimum wrapped around the record's end at
+    lengths just above multiples of 1024, whole-record palindromes, tandem repeats; odd seeds sprinkle 1 % N (the N build
+    and its exact resolution among sharers).  All three builds of the host API against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_fuzz.py"), seed, "6000", "leanties"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches: 0" in r.stdout

@@ -7,7 +7,10 @@ two-words-per-lane build of the streaming kernel; "nrich": half of the records c
 MODE_ALPHA: 4-bit register routine in the streaming kernel and the rescue pass; "longn": records of 1..9 kb with a few
 N -- the 2-bit-with-N-mask mode of the LDS tiers and its fallbacks; "prefixn": records of 0.4..6 kb without A except for
 planted A-runs followed by N / G / T / C, on both strands -- an N inside the minimal window and near-ties around it;
-"team": records of 15..700 kb -- the multi-wave team modes and their fallbacks)"""
+"team": records of 15..700 kb -- the multi-wave team modes and their fallbacks; "leanties": records of 1.0..20 kb -- the mixed
+kernel's lean routine and the cases it settles itself: the minimal 16-mer planted two to five times, a reverse-complement
+palindrome around it (both strands own it), lengths a little above multiples of 1024 with the minimum at the record's start
+or end (the periodic twin), whole-record palindromes and tandem repeats, half of the batches with 1 % N)"""
 import os
 import sys
 import time
@@ -47,6 +50,36 @@ if profile == "prefixn":
                 motif = motif.translate(comp)[::-1]
             bg[sp:sp + len(motif)] = motif
         seqs.append(bytes(bg))
+if profile == "leanties":
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    with_n = seed % 2 == 1
+    for i in range(count):
+        m = rng.integers(0, 100)
+        L = int(rng.integers(1009, 20400)) if m % 3 else int(rng.integers(1, 20)) * 1024 + int(rng.integers(-8, 40))
+        bg = bytearray(rng.choice(list(b"CGT"), size=L).astype(np.uint8).tobytes()) if m < 70 else bytearray(rand(L).tobytes())
+        if m < 25:                                                        # the minimal key several times
+            for sp in rng.integers(0, L - 16, size=int(rng.integers(2, 6))):
+                bg[sp:sp + 16] = b"A" * 16
+        elif m < 40:                                                      # a palindromic core that both strands own
+            half = b"A" * int(rng.integers(6, 10)) + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 5))).astype(np.uint8))
+            pal = half + half.translate(comp)[::-1]
+            sp = int(rng.integers(0, L - len(pal)))
+            bg[sp:sp + len(pal)] = pal
+        elif m < 55:                                                      # the minimum at the very start / end (wraps)
+            sp = int(rng.choice([0, 1, 5, 15, 16, L - 1, L - 2, L - 15, L - 16, L - 17]))
+            for k in range(17):
+                bg[(sp + k) % L] = ord("A")
+        elif m < 60:
+            half = rand(L // 2).tobytes()
+            bg = bytearray(half + half.translate(comp)[::-1])
+        elif m < 64:
+            unit = rand(int(rng.integers(50, 900))).tobytes()
+            bg = bytearray((unit * (L // len(unit) + 1))[:L])
+        if with_n:
+            for p_ in rng.integers(0, len(bg), size=max(1, len(bg) // 100)):
+                bg[int(p_)] = ord("N")
+        s_ = bytes(bg)
+        seqs.append(s_ if m % 2 else s_.translate(comp)[::-1])
 if profile == "team":
     # 15..700 kb: the team modes (four waves in tier A, sixteen in the last LDS stage) and what they leave to the general
     # routine -- a few N, tandem repeats, reverse-complement palindromes, gaps
@@ -68,7 +101,7 @@ if profile == "team":
                     a[int(rng.integers(0, L))] = ord("N") if rng.random() < 0.9 else ord("-")
             s = a.tobytes()
         seqs.append(s)
-for i in range(0 if profile in ("prefixn", "team") else count):
+for i in range(0 if profile in ("prefixn", "team", "leanties") else count):
     k = rng.integers(0, 100)
     if profile == "longn":
         L = int(rng.integers(1009, 9000)) if k < 90 else int(rng.integers(48, 1009))
