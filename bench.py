@@ -80,6 +80,8 @@ def main():
                          "the default 1 = strictly one batch after the other, so that the per-step time IS the kernel chain's time "
                          "and agrees with a rocprofv3 kernel trace of the same command")
     ap.add_argument("--max-len", type=int, default=20000, help="mixed: upper end of the log-uniform lengths (BASELINE configs[3]: 20000)")
+    ap.add_argument("--with-hash", action="store_true",
+                    help="mixed: also the XXH3 of every record and the first-seen resolution (`circkit uniq --canonicalize` on records of mixed lengths)")
     ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
                     help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
                          "strand duplicates, hash + first-seen); mixed = configs[3] (1M records, L ~ 1/L on [200, 20000])")
@@ -161,7 +163,7 @@ def main():
         c.set_stream(st.cuda_stream)
         with torch.cuda.stream(st):
             lane = {"ctx": c, "stream": st, "out": torch.empty(total + 64, dtype=torch.uint8, device=dev),
-                    "hash": torch.empty(N, dtype=torch.int64, device=dev) if args.workload == "uniq" else None, "fs": None, "keep": None}
+                    "hash": torch.empty(N, dtype=torch.int64, device=dev) if args.workload == "uniq" or args.with_hash else None, "fs": None, "keep": None}
             lane["table"] = U.DeviceTable(c)
         lanes.append(lane)
     d_out = lanes[0]["out"]
@@ -178,6 +180,9 @@ def main():
                 ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"], out_xxh3=ln["hash"])
                 ln["fs"], ln["keep"] = U.first_seen(ln["table"], ln["hash"], base_index=rank * N, exchange=args.exchange,
                                                     force_exchange=force_dist)
+            elif args.with_hash:
+                ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"], out_xxh3=ln["hash"])
+                ln["fs"], ln["keep"] = U.first_seen(ln["table"], ln["hash"], base_index=rank * N, exchange=args.exchange, force_exchange=force_dist)
             else:
                 ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"])
 
@@ -229,7 +234,7 @@ def main():
         # formula; the fraction with them is reported next to the judged one.
         algo_bytes = 2 * total + 8 * N
         table_bytes = 0
-        if args.workload == "uniq":
+        if args.workload == "uniq" or args.with_hash:
             algo_bytes += 8 * N
             table_bytes = 32 * N
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -261,9 +266,14 @@ def main():
             metric = "canonicalize sequences/sec (%d records, 200b-%dkb log-uniform lengths)" % (N, args.max_len // 1000)
             wl = "canonicalize, %d records, lengths log-uniform on [200, %d], %d bases per GPU%s (%s)" % (
                 N, args.max_len, total, nvar, "BASELINE configs[3]" if (N, args.max_len) == (1_000_000, 20000) and not nvar else "variant of BASELINE configs[3]")
-            kernel = ("canon_mixed_kernel<%s> (whole step; per-kernel split in profiles/)" % ("true" if nvar else "false"))
+            build = {(False, False): "canon_mixed_kernel", (True, False): "canon_mixed_n_kernel", (False, True): "canon_mixed_h_kernel",
+                     (True, True): "canon_mixed_nh_kernel"}[(bool(nvar), args.with_hash)]
+            kernel = build + (" + uniq_resolve_insert_kernel + uniq_resolve_lookup_kernel" if args.with_hash else "") + " (whole step; per-kernel split in profiles/)"
+            if args.with_hash:
+                metric = "uniq --canonicalize sequences/sec (%d records, 200b-%dkb log-uniform lengths, all distinct)" % (N, args.max_len // 1000)
+                wl = wl.replace("canonicalize,", "canonicalize + XXH3 + first-seen,")
             par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
-        traffic, traffic_source = pmc_traffic("%s %d x %d" % (args.workload, N, L) + (" n%g" % args.n_frac if nvar else ""))
+        traffic, traffic_source = pmc_traffic("%s %d x %d" % (args.workload, N, L) + (" n%g" % args.n_frac if nvar else "") + (" hash" if args.with_hash else ""))
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes}
@@ -347,7 +357,7 @@ def end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out):
     h_in = torch.frombuffer((ctypes.c_uint8 * nb).from_address(pin_in), dtype=torch.uint8)
     h_in.copy_(d_bytes[first:first + nb])
     torch.cuda.synchronize()
-    want_hash = args.workload == "uniq"
+    want_hash = args.workload == "uniq" or args.with_hash
     h_hash = np.empty(S, dtype=np.uint64) if want_hash else None
 
     def call():
@@ -394,7 +404,7 @@ def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
     nb = int(h_off[-1])
     h_in = d_bytes[:nb].cpu().numpy()
     O.lib()
-    want_hash = args.workload == "uniq"
+    want_hash = args.workload == "uniq" or args.with_hash
     c0 = time.perf_counter()
     h_out, h_hash = O.canonicalize_batch(h_in, h_off, True, want_hash, threads=cores)
     fs = O.uniq_first_seen(h_hash) if want_hash else None          # single thread, as the reference's main-thread closure

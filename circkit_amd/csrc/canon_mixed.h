@@ -280,14 +280,76 @@ CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom& g, co
     return best;
 }
 
+// ---- XXH3-64 fused into the lean routine's output loop (HASH builds, pure records of more than 240 symbols) ----------------
+// Replaces `xxh3_64(canonicalized)` (src/uniq.rs:45) for the records of a mixed-length batch: `circkit uniq` on contigs of
+// mixed lengths went rescue pass + general LDS routine + a pass of the xxh3 kernel over the output (round 2 / 3 first half:
+// 5.0 ms for config 4's batch against 1.8 ms for the bytes alone).  The output loop's row of 64 chunks IS one 1024-byte XXH3
+// block -- lane = (stripe lane >> 2, accumulator pair lane & 3), the layout of canon_fast.h fast_hash -- so every row adds
+// its cells' products to the accumulators, full blocks are followed by XXH3's scramble, and the last stripe, the merge and
+// the avalanche follow behind the loop.  Per-pair constants live in a 64-dword LDS table (lean_hash_table_init: last-stripe
+// and merge secrets, initial accumulators, scramble secrets); the per-lane stripe secrets stay in registers.
+constexpr uint32_t LEAN_HASH_TABLE_DW = 64;          // per pair j (16 dwords): l0 l1 m0 m1 i0 i1 sc0 sc1
+CK_DEV void lean_hash_table_init(uint32_t* tab, uint32_t tid)
+{
+    if (tid < 4) {
+        const uint32_t j = tid;
+        const uint64_t v[8] = { xsec64(121 + 16 * j), xsec64(129 + 16 * j), xsec64(11 + 16 * j), xsec64(19 + 16 * j),
+                                j == 0 ? XP32_3 : j == 1 ? XP64_2 : j == 2 ? XP64_4 : XP64_5,
+                                j == 0 ? XP64_1 : j == 1 ? XP64_3 : j == 2 ? XP32_2 : XP32_1,
+                                xsec64(128 + 16 * j), xsec64(136 + 16 * j) };
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { tab[16 * j + 2 * k] = (uint32_t)v[k]; tab[16 * j + 2 * k + 1] = (uint32_t)(v[k] >> 32); }
+    }
+}
+CK_DEV uint64_t lean_hash_const(const uint32_t* tab, uint32_t k) { const uint32_t j = lane_id() & 3; return ((uint64_t)tab[16 * j + 2 * k + 1] << 32) | tab[16 * j + 2 * k]; }
+// the register routine's per-lane constants other than the stripe secrets, fetched from the table when a short record is at
+// hand instead of living in sixteen registers across the kernel's loop
+CK_DEV void lean_hash_refill(FastHashConst& hc, const uint32_t* tab)
+{
+    hc.l0 = lean_hash_const(tab, 0); hc.l1 = lean_hash_const(tab, 1);
+    hc.m0 = lean_hash_const(tab, 2); hc.m1 = lean_hash_const(tab, 3);
+    hc.i0 = lean_hash_const(tab, 4); hc.i1 = lean_hash_const(tab, 5);
+}
+struct LeanHash { uint64_t a0, a1, k0, k1; };         // accumulators of pair lane & 3 (meaningful where (lane & 15) >= 12), the lane's stripe secrets
+// one row (= block `b`) of cells: `cell` = this lane's 16 output bytes at chunk 64 b + lane, counted iff its stripe is one of
+// the `total_stripes` full stripes in front of the last one
+CK_DEV void lean_hash_row(LeanHash& h, const uint32_t* tab, u32x4 cell, uint32_t w, uint32_t total_stripes, bool scramble)
+{
+    const uint64_t d0 = ((uint64_t)cell.y << 32) | cell.x, d1 = ((uint64_t)cell.w << 32) | cell.z;
+    const uint64_t x0 = d0 ^ h.k0, x1 = d1 ^ h.k1;
+    const bool on = (w >> 2) < total_stripes;
+    uint64_t c0 = on ? d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32) : 0;
+    uint64_t c1 = on ? d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32) : 0;
+    dpp_rowsum4_u64x2(c0, c1);
+    c0 = shfl_xor_add64(c0, 16); c1 = shfl_xor_add64(c1, 16);
+    c0 = shfl_xor_add64(c0, 32); c1 = shfl_xor_add64(c1, 32);
+    h.a0 += c0; h.a1 += c1;
+    if (scramble) {                                   // (uniform) a full block: scramble with the last 64 secret bytes
+        h.a0 = (h.a0 ^ (h.a0 >> 47) ^ lean_hash_const(tab, 6)) * XP32_1;
+        h.a1 = (h.a1 ^ (h.a1 >> 47) ^ lean_hash_const(tab, 7)) * XP32_1;
+    }
+}
+// last stripe (the final 64 bytes: pair j = bytes [n - 64 + 16 j, + 16), given as `cell`), merge, avalanche; same in every lane
+CK_DEV uint64_t lean_hash_finish(LeanHash& h, const uint32_t* tab, u32x4 cell, uint32_t n)
+{
+    const uint64_t d0 = ((uint64_t)cell.y << 32) | cell.x, d1 = ((uint64_t)cell.w << 32) | cell.z;
+    const uint64_t x0 = d0 ^ lean_hash_const(tab, 0), x1 = d1 ^ lean_hash_const(tab, 1);
+    h.a0 += d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32);
+    h.a1 += d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32);
+    uint64_t r = xfold(h.a0 ^ lean_hash_const(tab, 2), h.a1 ^ lean_hash_const(tab, 3));
+    r = dpp_quadsum_u64(r);
+    const uint64_t v = xaval3((uint64_t)n * XP64_1 + r);
+    return ((uint64_t)readlane((uint32_t)(v >> 32), 15) << 32) | readlane((uint32_t)v, 15);
+}
+
 // One record of more than FAST_MAX_N symbols in the wave's slice.  0: done; 1: not this routine's alphabet (stage A is told);
 // 2: pure as far as seen, but a tie / equal strands / no room (stage A's general routine).
 #ifndef CK_LEAN_MIN_PREFIX
 #define CK_LEAN_MIN_PREFIX 6      // prefix rule: with fewer deciding symbols than this some other rotation shares them anyway (4^6 against ~10^4 rotations)
 #endif
-template <bool NM>
+template <bool NM, bool HASH = false>
 CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uint32_t n, uint64_t payload_end, uint32_t* slice,
-                             const uint32_t* lut)
+                             const uint32_t* lut, const uint32_t* htab = nullptr, uint64_t hk0 = 0, uint64_t hk1 = 0)
 {
     const uint32_t lane = lane_id();
     LeanGeom g;
@@ -385,28 +447,46 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
             }
         }
     }
-    if (a.out_bytes) {
-        uint8_t* out = a.out_bytes + off;
-        // (two loops: the strand is the same for the whole record, and a select inside one loop computed both strands' words)
-        if (fwd) {
-            for (uint32_t w = lane; 16 * w < n; w += 64) {
-                const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16;          // the last window is pulled back to end at n
-                uint32_t p = idx + o;
-                p = p >= n ? p - n : p;
-                store16(out + o, fast_decode(lut, lean_window(E, (int32_t)(p + g.a16))));
+    // XXH3 fused (HASH builds): pure records of more than 240 symbols; what is not fused -- the N build's records (their
+    // bytes are patched behind the stores), the short-input classes -- is the xxh3 pass's, from the bytes or, when no bytes
+    // were asked for, from the view
+    const bool fused = HASH && !NM && a.out_hash != nullptr && n > 240;
+    if (HASH && !fused && a.out_view && lane == 0) a.out_view[rec] = fwd ? idx : (idx | 0x80000000u);
+    if (a.out_bytes || fused) {
+        uint8_t* out = a.out_bytes ? a.out_bytes + off : nullptr;
+        // the 16 output bytes at output offset o (the strand is the same for the whole record: two loops, a select inside one
+        // loop computed both strands' words)
+        const auto cell_at = [&](uint32_t o, bool f) {
+            uint32_t p = idx + o;
+            p = p >= n ? p - n : p;
+            if (f) return fast_decode(lut, lean_window(E, (int32_t)(p + g.a16)));
+            const uint32_t s = (p + 16 <= n ? n - 16 - p : 2 * n - 16 - p) + g.a16;       // LDS index of the forward window behind them
+            return fast_decode(lut, rc_word<2>(lean_window(E, (int32_t)s)));
+        };
+        if (!fused) {
+            if (fwd) { for (uint32_t w = lane; 16 * w < n; w += 64) { const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16; store16(out + o, cell_at(o, true)); } }
+            else { for (uint32_t w = lane; 16 * w < n; w += 64) { const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16; store16(out + o, cell_at(o, false)); } }
+        } else if constexpr (HASH && !NM) {
+            LeanHash h;
+            h.a0 = lean_hash_const(htab, 4); h.a1 = lean_hash_const(htab, 5);
+            h.k0 = hk0; h.k1 = hk1;                                                // (the lane's stripe secrets: FastHashConst::k0 / k1)
+            const uint32_t total_stripes = (n - 1) >> 6, nb = (n - 1) >> 10;
+            for (uint32_t b = 0; b <= nb; ++b) {                                   // (uniform: a row of 64 chunks = one XXH3 block)
+                const uint32_t w = 64 * b + lane;
+                u32x4 cell{ 0, 0, 0, 0 };
+                if (16 * w < n) {
+                    const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16;         // the last window is pulled back to end at n
+                    cell = fwd ? cell_at(o, true) : cell_at(o, false);
+                    if (out) store16(out + o, cell);
+                }
+                lean_hash_row(h, htab, cell, w, total_stripes, b < nb);           // (a counted cell is a full chunk: o = 16 w)
             }
-        } else {
-            for (uint32_t w = lane; 16 * w < n; w += 64) {
-                const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16;
-                uint32_t p = idx + o;
-                p = p >= n ? p - n : p;
-                // LDS index of the forward window behind the 16 output symbols
-                const uint32_t s = (p + 16 <= n ? n - 16 - p : 2 * n - 16 - p) + g.a16;
-                store16(out + o, fast_decode(lut, rc_word<2>(lean_window(E, (int32_t)s))));
-            }
+            const u32x4 last = fwd ? cell_at(n - 64 + 16 * (lane & 3), true) : cell_at(n - 64 + 16 * (lane & 3), false);
+            const uint64_t hv = lean_hash_finish(h, htab, last, n);
+            if (lane == 0) { a.out_hash[rec] = hv; a.hashed[rec] = 1; }
         }
         if constexpr (NM) {
-            if (n_n) {
+            if (n_n && out) {
                 // the decoded G (forward) / C (reverse) of every listed position becomes N: single-byte stores BEHIND the
                 // 16-byte stores that cover the same bytes (vmcnt(0): those have been performed)
                 wave_sync();
@@ -439,20 +519,24 @@ CK_DEV MixedNext mixed_fetch(const CanonArgs& a, uint32_t rec)
     return m;
 }
 // a pure-ACGT record of 48..1008 symbols through the register routine (canon_stream.h rescue_direct with the bytes at hand)
-CK_DEV bool mixed_short(const CanonArgs& a, const uint32_t* lut, RescueState<false, false>& st, uint32_t rec, const MixedNext& m, bool& not_acgt)
+template <bool HASH>
+CK_DEV bool mixed_short(const CanonArgs& a, const uint32_t* lut, RescueState<HASH, false>& st, uint32_t rec, const MixedNext& m, bool& not_acgt, const uint32_t* htab)
 {
+    if constexpr (HASH) lean_hash_refill(st.hc, htab);
     const uint32_t n = (uint32_t)m.len, nwf = n >> 4, t = lane_id();
     uint32_t miss;
     uint32_t F = fast_pack(m.v, miss);
     F <<= t >= nwf ? ((16 - (n & 15)) & 15) * 2 : 0;
     const uint64_t bad = ballot(miss != 0);
     not_acgt = bad != 0;
-    return fast_canon<false, false>(a, lut, st.hc, st.shape, rec, m.off, n, F, bad);
+    return fast_canon<HASH, false>(a, lut, st.hc, st.shape, rec, m.off, n, F, bad);
 }
 // the same over ACGTN (the rescue pass's rescue_one without the list): the N-mask variant of fast_canon, then the 4-bit
 // routine for what it refuses
-CK_DEV bool mixed_short_n(const CanonArgs& a, const uint32_t* lut, RescueState<false, false>& st, uint32_t rec, const MixedNext& m)
+template <bool HASH>
+CK_DEV bool mixed_short_n(const CanonArgs& a, const uint32_t* lut, RescueState<HASH, false>& st, uint32_t rec, const MixedNext& m, const uint32_t* htab)
 {
+    if constexpr (HASH) lean_hash_refill(st.hc, htab);
     const uint32_t n = (uint32_t)m.len, nwf = n >> 4, t = lane_id();
     const uint32_t tail_syms = t >= nwf ? (16 - (n & 15)) & 15 : 0;       // the tail lane's symbols move up by this much
     uint32_t nm, miss;
@@ -461,22 +545,24 @@ CK_DEV bool mixed_short_n(const CanonArgs& a, const uint32_t* lut, RescueState<f
     const uint64_t bad = ballot(miss != 0), with_n = ballot(nm != 0);
     bool done = false;
     if (bad == 0) {
-        if (with_n == 0) done = fast_canon<false, false>(a, lut, st.hc, st.shape, rec, m.off, n, F, 0);
-        else done = fast_canon<false, false, false, false, true>(a, lut, st.hc, st.shape, rec, m.off, n, F, 0, nullptr, nm);
+        // (HASH builds: the N-mask variant of the register routine writes bytes only -- records with an N take the 4-bit
+        // routine, whose bytes the xxh3 pass hashes)
+        if (with_n == 0) done = fast_canon<HASH, false>(a, lut, st.hc, st.shape, rec, m.off, n, F, 0);
+        else if constexpr (!HASH) done = fast_canon<false, false, false, false, true>(a, lut, st.hc, st.shape, rec, m.off, n, F, 0, nullptr, nm);
     }
     if (!done && (bad | with_n) != 0) {
         uint32_t H, L, bad4;
         fast_pack4(m.v, H, L, bad4);
         const uint64_t x = ((((uint64_t)H) << 32) | L) << (4 * tail_syms);
-        done = fast_canonw<4, false, false>(a, lut, st.hc, rec, m.off, n, (uint32_t)(x >> 32), (uint32_t)x, ballot(bad4 != 0) != 0);
+        done = fast_canonw<4, HASH, false>(a, lut, st.hc, rec, m.off, n, (uint32_t)(x >> 32), (uint32_t)x, ballot(bad4 != 0) != 0);
     }
     return done;
 }
 
 // One wave's share of segment `sgm` of a mode-3 batch: records [sgm * all_seg_cap, ...), every wpb-th from wib on.
-template <bool NM>
-CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint32_t* lut, RescueState<false, false>& st,
-                                uint32_t* blk_count, uint32_t sgm, uint32_t wib, uint32_t wpb, uint64_t payload_end)
+template <bool NM, bool HASH = false>
+CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint32_t* lut, RescueState<HASH, false>& st,
+                                uint32_t* blk_count, uint32_t sgm, uint32_t wib, uint32_t wpb, uint64_t payload_end, const uint32_t* htab = nullptr)
 {
     const uint64_t first = (uint64_t)sgm * a.all_seg_cap;
     const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap));
@@ -495,13 +581,13 @@ CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint3
         const uint64_t off = cur.off, len = cur.len;
         bool not_acgt = false, tried = false;
         if (len >= FAST_MIN_N && len <= FAST_MAX_N) {
-            if constexpr (NM) { if (mixed_short_n(a, lut, st, rec, cur)) continue; tried = true; }
-            else { if (mixed_short(a, lut, st, rec, cur, not_acgt)) continue; }
+            if constexpr (NM) { if (mixed_short_n<HASH>(a, lut, st, rec, cur, htab)) continue; tried = true; }
+            else { if (mixed_short<HASH>(a, lut, st, rec, cur, not_acgt, htab)) continue; }
         }
         // longer records -- and (pure build) the few short ones the register routine leaves (a tied minimal key, a minimal key
         // both strands own): the lean LDS routine
         if (len >= FAST_MIN_N && len < (1ull << 31) && !not_acgt && !tried) {
-            const int r = canon_lean_record<NM>(a, rec, off, (uint32_t)len, payload_end, slice, lut);
+            const int r = canon_lean_record<NM, HASH>(a, rec, off, (uint32_t)len, payload_end, slice, lut, htab, st.hc.k0, st.hc.k1);
             wave_sync();                                    // every lane is done with the slice before the next record's build
             if (r == 0) continue;
             not_acgt = NM || r == 1;

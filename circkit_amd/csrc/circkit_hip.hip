@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
-    if (!AUX && !HASH && (mode & 3) == 3) return;                        // ... or canon_mixed_kernel (either alphabet)
+    if (!AUX && (mode & 3) == 3) return;                                 // ... or a canon_mixed kernel (either alphabet, with or without the XXH3)
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
     const bool all_records = (mode & 3) == 3;                           // the streaming kernel stood this batch out
     if (!all_records) {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 // amdgpu_num_vgpr(36): on gfx90a+ the attribute counts in the unified VGPR + AGPR file at twice the value -- 72 registers,
 // seven waves per SIMD, as __launch_bounds__(256, 7) would give, but WITHOUT that bound's cut of the scalar registers to 94
 // (the trap handler's 16 are taken off 800 / 7 before rounding down): 102 are addressable at that occupancy.
-template <bool NM>
+template <bool NM, bool HASH>
 __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out, uint32_t* tiers_busy)
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
@@ -380,8 +380,14 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + 4 * a.slice_dw;
     uint32_t* lut = blk_count + 4;
+    uint32_t* htab = lut + ck::FAST_LUT_DW;                // (HASH builds: the XXH3 per-pair constants, in the place of the tiers' N patch table + 48 dwords)
     ck::fast_lut_init(lut, threadIdx.x, 256);
-    ck::RescueState<false, false> st;
+    if (HASH) ck::lean_hash_table_init(htab, threadIdx.x);
+    ck::RescueState<HASH, false> st;
+    if (HASH) {                                          // (only the lane's stripe secrets stay in registers: lean_hash_refill)
+        st.hc.k0 = ck::xsec64(8 * (ck::lane_id() >> 2) + 16 * (ck::lane_id() & 3));
+        st.hc.k1 = ck::xsec64(8 * (ck::lane_id() >> 2) + 16 * (ck::lane_id() & 3) + 8);
+    }
     const uint32_t wib = ck::uniform(threadIdx.x >> 6);
     uint32_t* slice = lds + wib * a.slice_dw;
     const uint64_t payload_end = a.offsets[a.n_records];
@@ -389,7 +395,7 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
         if (threadIdx.x == 0) { blk_count[0] = 0; blk_count[1] = 0; }
         __syncthreads();
-        ck::canon_mixed_segment<NM>(a, slice, lut, st, blk_count, sgm, wib, 4, payload_end);
+        ck::canon_mixed_segment<NM, HASH>(a, slice, lut, st, blk_count, sgm, wib, 4, payload_end, htab);
         __syncthreads();
         if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
     }
@@ -398,19 +404,23 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
 #ifndef CK_MIXED_NM_VGPR
 #define CK_MIXED_NM_VGPR 36
 #endif
+#ifndef CK_MIXED_H_VGPR
+#define CK_MIXED_H_VGPR 40       // the builds with the fused XXH3: 80 registers, six waves per SIMD
+#endif
 #ifndef CK_MIXED_N_SLICE
 #define CK_MIXED_N_SLICE 1596     // dwords per wave of canon_mixed_n_kernel: six workgroups per CU (measured: 1368 = seven workgroups 2.38 ms, 1596 2.33 -- the N list of a 20 kb record needs the room)
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(36))) void canon_mixed_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode,
-                                                                                             uint32_t* mode_out, uint32_t* tiers_busy)
-{
-    canon_mixed_body<false>(a, mode_word, host_mode, mode_out, tiers_busy);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(CK_MIXED_NM_VGPR))) void canon_mixed_n_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode_word, uint32_t host_mode,
-                                                                                                             uint32_t* mode_out, uint32_t* tiers_busy)
-{
-    canon_mixed_body<true>(a, mode_word, host_mode, mode_out, tiers_busy);
-}
+#define CK_MIXED_KERNEL(NAME, NM, HASH, VGPR)                                                                                                  \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VGPR))) void NAME(ck::CanonArgs a, const uint32_t* __restrict__ mode_word,   \
+                                                                                     uint32_t host_mode, uint32_t* mode_out, uint32_t* tiers_busy) \
+    {                                                                                                                                          \
+        canon_mixed_body<NM, HASH>(a, mode_word, host_mode, mode_out, tiers_busy);                                                             \
+    }
+CK_MIXED_KERNEL(canon_mixed_kernel, false, false, 36)
+CK_MIXED_KERNEL(canon_mixed_n_kernel, true, false, CK_MIXED_NM_VGPR)
+CK_MIXED_KERNEL(canon_mixed_h_kernel, false, true, CK_MIXED_H_VGPR)          // + XXH3 (uniq on batches of mixed lengths)
+CK_MIXED_KERNEL(canon_mixed_nh_kernel, true, true, CK_MIXED_H_VGPR)
+#undef CK_MIXED_KERNEL
 
 // GH: the fused XXH3 is finished per 16-record group by one wave (canon_fast.h group_hash_*): 18.2 KiB more LDS, which
 // the ROWS = 2 build cannot afford next to its 64 KiB of images (two workgroups per CU are what matters most).
@@ -1078,7 +1088,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         uint32_t* mode_out = c->d_mode;               // straight into pinned host memory: no copy-back, no event
 #endif
         // both alphabets' builds unless the host has decided; the one the mode does not name returns at once
-        const bool mixed_has_it = host_mode && !aux && !d_hash && (host_mode & 3) == 3;
+        const bool mixed_has_it = host_mode && !aux && (host_mode & 3) == 3;
         const bool lean = (!host_mode || !(host_mode & MODE_ALPHA)) && !mixed_has_it, alpha = (!host_mode || (host_mode & MODE_ALPHA)) && !mixed_has_it;
         if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         else if (d_hash) {
@@ -1089,7 +1099,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
         }
     }
-    if (!aux && !d_hash && (!host_mode || (host_mode & 3) == 3)) {
+    if (!aux && (!host_mode || (host_mode & 3) == 3)) {
         // mode 3: canon_mixed_kernel takes every record (the rescue pass above stood out); same lists, same segments.  Both
         // alphabets' builds unless the host has decided; one workgroup per segment for the build the previous batch used,
         // a small walking grid for the other (it returns at once unless the expectation was wrong).
@@ -1112,9 +1122,14 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             // the N build keeps a list of the record's N positions (and lean_resolve_n's candidates) behind the strand: a bigger
             // slice (six workgroups = 24 waves per CU), so that a 20 kb record of config 4 has room for the ~200 N it holds at 1 %
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
-            const size_t shmem = (4 * a.slice_dw + TIER_EXTRA_DW) * 4;
-            if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
-            else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            const size_t shmem = (4 * a.slice_dw + 4 + ck::FAST_LUT_DW + (d_hash ? ck::LEAN_HASH_TABLE_DW : 0)) * 4;
+            if (d_hash) {
+                if (nm) hipLaunchKernelGGL(canon_mixed_nh_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+                else hipLaunchKernelGGL(canon_mixed_h_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            } else {
+                if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+                else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            }
         }
     }
 #ifdef CK_DEBUG_DUMP

@@ -140,15 +140,24 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false, solo = true; };
-void mixed_body(void* p)         // one fiber of a 4-wave workgroup of canon_mixed_kernel<NM> (NM = the batch's MODE_ALPHA)
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false, solo = true; const uint32_t* htab = nullptr; };
+void mixed_body(void* p)         // one fiber of a 4-wave workgroup of canon_mixed[_n][_h]_kernel (NM = the batch's MODE_ALPHA, HASH = out_hash given)
 {
     Launch* L = (Launch*)p;
     const uint32_t wib = ck::emu::cur_wave();
-    ck::RescueState<false, false> st;
     const uint64_t payload_end = L->a.offsets[L->a.n_records];
-    if (L->alpha) ck::canon_mixed_segment<true>(L->a, L->lds + wib * L->a.slice_dw, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
-    else ck::canon_mixed_segment<false>(L->a, L->lds + wib * L->a.slice_dw, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
+    uint32_t* slice = L->lds + wib * L->a.slice_dw;
+    if (L->a.out_hash) {
+        ck::RescueState<true, false> st;
+        st.hc.k0 = ck::xsec64(8 * (ck::lane_id() >> 2) + 16 * (ck::lane_id() & 3));
+        st.hc.k1 = ck::xsec64(8 * (ck::lane_id() >> 2) + 16 * (ck::lane_id() & 3) + 8);
+        if (L->alpha) ck::canon_mixed_segment<true, true>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end, L->htab);
+        else ck::canon_mixed_segment<false, true>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end, L->htab);
+    } else {
+        ck::RescueState<false, false> st;
+        if (L->alpha) ck::canon_mixed_segment<true, false>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
+        else ck::canon_mixed_segment<false, false>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
+    }
 }
 void wave_body(void* p)          // one fiber of a 4-wave workgroup of the LDS tier (canon_kernel<4>)
 {
@@ -260,7 +269,10 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     L.a.list = list_f.data(); L.a.list_count = cnt_f.data(); L.a.in_nseg = G; L.a.in_seg_cap = cap; L.a.segs_per_block = 1; L.a.all_seg_cap = cap;
     L.a.defer_list = list_r.data(); L.a.defer_count = cnt_r.data(); L.a.out_seg_cap = cap;
     // launch_canon: a mode-3 batch that wants bytes only is canon_mixed_kernel's (bit 2 of `alpha` selects it here)
-    const bool mixed = all_records && (alpha & 4) && !out_index && !out_strand && !out_hash && !(flags & ck::CK_FLAG_FWD_ONLY);
+    const bool mixed = all_records && (alpha & 4) && !out_index && !out_strand && !(flags & ck::CK_FLAG_FWD_ONLY);
+    uint32_t htab[ck::LEAN_HASH_TABLE_DW];
+    for (uint32_t tid = 0; tid < 4; ++tid) ck::lean_hash_table_init(htab, tid);
+    L.htab = htab;
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;
         L.block = b; L.blk_count = &blk;

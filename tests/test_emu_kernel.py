@@ -715,3 +715,33 @@ def test_mixed_kernel_n_inside_the_minimal_window_is_resolved_among_the_sharers(
         a, b = int(offs[i]), int(offs[i + 1])
         assert out[a:b].tobytes() == want[i], (i, len(s))
     assert emu.last_rescued_count >= len(seqs) - 8
+
+
+@pytest.mark.parametrize("with_n,hash_only", [(False, False), (False, True), (True, False), (True, True)])
+def test_mixed_kernel_with_fused_xxh3(with_n, hash_only):
+    """canon_mixed_h_kernel / canon_mixed_nh_kernel (`circkit uniq` on records of mixed lengths): the lean routine's output
+    loop accumulates XXH3 block by block (a row of 64 chunks = one 1024-byte block, scramble behind every full one), for
+    pure records of more than 240 symbols; N records, the short-input classes and everything stage A takes are hashed by
+    the xxh3 pass -- from the bytes, or (hash_only: no bytes asked for) from their views.  Lengths around every block and
+    stripe boundary."""
+    import random
+    rng = random.Random(515)
+    seqs = _mixed_batch(5150, with_n)
+    for n in (241, 255, 256, 257, 1009, 1023, 1024, 1025, 1087, 1088, 1089, 2047, 2048, 2049, 2111, 2112, 2113, 3072, 3073, 4095, 4096, 4097, 5121):
+        seqs.append(seqsets.rand_seq(rng, n))
+        seqs.append(seqsets.revcomp_acgt(seqsets.rand_seq(rng, n, b"CGT") + b"A" * 17))
+    rng.shuffle(seqs)
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s)[0] for s in seqs]
+    out, _, _, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=True, want_aux=False, staged=0, slice_dw=1596 if with_n else 1280, n_waves=12,
+                                                        alpha=with_n, mixed=True, hash_only=hash_only, base_shift=7)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        if not hash_only:
+            assert out[a:b].tobytes() == want[i], (i, len(s))
+        assert int(h[i]) == O.xxh3_64(want[i]), (i, len(s))
+    if hash_only:
+        assert (out == 0x3F).all()
+    if not with_n:
+        assert emu.last_fused_hash_count >= 60                           # the long pure records' hashes are the lean routine's own

@@ -100,6 +100,22 @@ def test_mixed_config4_full_size(ctx, O, n_frac):
     ctx.canonicalize_batch_device(y, off, N, out_bytes=c3)
     torch.cuda.synchronize()
     assert torch.equal(c1[:total], c3[:total]), "canonical form changed under reverse complement + rotation"
+    del c3
+    # `uniq` on the same batch (round 3: the mixed kernels' builds with the fused XXH3): hashes of bytes + hash and of the
+    # hash-only call agree with each other over all records, with the oracle on the slice; the reverse-complemented /
+    # rotated batch hashes to the same values (that is what makes them duplicates, src/uniq.rs:45-48)
+    h1 = torch.zeros(N, dtype=torch.int64, device=dev)
+    h2 = torch.zeros(N, dtype=torch.int64, device=dev)
+    h3 = torch.zeros(N, dtype=torch.int64, device=dev)
+    c4 = torch.full_like(x, 0x3F)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=c4, out_xxh3=h1)
+    ctx.canonicalize_batch_device(x, off, N, out_xxh3=h2)
+    ctx.canonicalize_batch_device(y, off, N, out_xxh3=h3)
+    assert ctx.batch_status() == 0
+    assert torch.equal(c1[:total], c4[:total])
+    assert torch.equal(h1, h2) and torch.equal(h1, h3)
+    _, exp_h = O.canonicalize_batch(x[:nb].cpu().numpy(), h_off, False, True, threads=8)
+    assert np.array_equal(h1[:S].cpu().numpy().astype(np.uint64), exp_h)
 
 
 def test_one_percent_n_headline_shape(ctx, O):

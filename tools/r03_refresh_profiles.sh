@@ -35,6 +35,7 @@ run uniq --workload uniq
 run mixed --workload mixed
 run canonicalize_n1pct --n-frac 0.01
 run mixed_n1pct --workload mixed --n-frac 0.01
+run mixed_uniq --workload mixed --with-hash
 # the multi-GPU uniq exchange rehearsed on one GPU (launcher + RCCL, one rank)
 CIRCKIT_BENCH_FORCE_DIST=1 python bench.py --workload uniq --no-cpu --no-e2e > $O/r03_bench_uniq_forced_exchange.json 2>/dev/null
 # the same three workloads with the steps dealt to three ctx/stream lanes (bench lines only: overlapping launches make
