@@ -261,7 +261,7 @@ CK_DEV void fast_shape(FastShape& sh, uint32_t n)
 // canon_record_mode2n is the same idea in the LDS tiers.)
 template <bool HASH, bool AUX, bool GH = false, bool K16 = false, bool NM = false>
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
-                       uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr, uint32_t Nm = 0)
+                       uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr, uint32_t Nm = 0, uint32_t* view_out = nullptr)
 {
     static_assert(!NM || (!HASH && !AUX), "the N-mask variant writes bytes only");
     const uint32_t t = lane_id();
@@ -385,6 +385,7 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         if (a.out_strand) a.out_strand[rec] = fwd ? 0 : 1;
     }
     if (HASH && a.out_view && n <= 240 && t == 0) a.out_view[rec] = fwd ? idx : (idx | 0x80000000u);      // hash not fused: the xxh3 pass reads the view
+    if (view_out) *view_out = fwd ? idx : (idx | 0x80000000u);     // (callers that hash the short-input classes themselves: canon_mixed.h)
     return true;
 }
 
