@@ -486,18 +486,23 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
         }
         return;
     }
-    // 512 flags per look (8 per lane, one 8-byte load: the flag array is 8-byte aligned and padded): an all-hashed batch of
+    // A wave looks at `span` consecutive records at a time: 512 (8 flags per lane) when the batch is big enough to keep every wave
+    // busy that way, fewer -- a multiple of 64 -- for smaller batches: with 512 a million-record batch of mixed lengths whose
+    // hashes are all still to do (the N build of the mixed kernel) kept a quarter of the waves busy, 2.85 ms for 4.3 GB.
+    const uint64_t per_wave = (n_records + n_waves - 1) / n_waves;
+    const uint32_t span = per_wave >= 512 ? 512u : (per_wave <= 64 ? 64u : (uint32_t)((per_wave + 63) / 64) * 64u);
+    // up to 512 flags per look (8 per lane, one 8-byte load: the flag array is 8-byte aligned and padded): an all-hashed batch of
     // 10M records is 2-3 dependent loads per wave instead of 19 (28 -> ~8 us per batch)
-    for (uint64_t big = (uint64_t)wave * 512; big < n_records; big += (uint64_t)n_waves * 512) {
+    for (uint64_t big = (uint64_t)wave * span; big < n_records; big += (uint64_t)n_waves * span) {
       const uint64_t f0 = big + 8 * ck::lane_id();
       uint64_t flags8 = ~0ull;
-      if (f0 < n_records) {
+      if (f0 < n_records && 8 * ck::lane_id() < span) {
           flags8 = *reinterpret_cast<const uint64_t*>(hashed + f0);
           if (n_records - f0 < 8) flags8 |= ~0ull << (8 * (n_records - f0));       // bytes past the last record
       }
       // a zero byte = a record still to hash
       if (ck::ballot(((flags8 - 0x0101010101010101ull) & ~flags8 & 0x8080808080808080ull) != 0) == 0) continue;
-      for (uint64_t base = big; base < big + 512 && base < n_records; base += 64) {
+      for (uint64_t base = big; base < big + span && base < n_records; base += 64) {
         const uint64_t mine = base + ck::lane_id();
         const bool need = mine < n_records && !hashed[mine];
         uint64_t todo = ck::ballot(need);
