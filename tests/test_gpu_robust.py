@@ -112,3 +112,33 @@ def test_hash_only_device_batches_enqueue_without_a_look_at_the_device(O):
         bad = np.nonzero(got != exp_h)[0]
         assert len(bad) == 0, (len(bad), bad[:5], [int(offs[i + 1] - offs[i]) for i in bad[:5]])
     ctx.close()
+
+
+@pytest.mark.parametrize("parts", ["1", "2", "3", "8"])
+def test_host_batch_in_parts(O, parts):
+    """circkit_canonicalize_batch moves a host batch through the device in parts (copy-in / kernels / copy-out of
+    neighbouring parts overlap on the ctx's own copy streams; 16 MB and more per part by default, forced here on a small
+    batch): every output of every part lands in its place -- bytes, index, strand, hash against the oracle --, with records of
+    all alphabets and lengths so that the parts differ in what their kernels do, and a second call right behind the first."""
+    import circkit_amd
+    from tests import seqsets
+    os.environ["CIRCKIT_HOST_BATCH_PARTS"] = parts
+    try:
+        ctx = circkit_amd.Context(0)
+        seqs = seqsets.random_mixed(900, 700, 900, 1008) + seqsets.random_mixed(901, 60, 1009, 12000) + seqsets.random_mixed(902, 100, 1, 300) + \
+            seqsets.random_mixed(903, 80, 48, 2000, b"ACGTN") + seqsets.random_mixed(904, 30, 10, 400, b"-ACGNT") + [b"", b"A" * 5000, b"ACGT" * 700]
+        for rnd in range(2):
+            rng = np.random.default_rng(rnd)
+            batch = [seqs[i] for i in rng.permutation(len(seqs))]
+            data, offs = seqsets.pack(batch)
+            got = ctx.canonicalize_batch(data, offs, want_bytes=True, want_index=True, want_strand=True, want_xxh3=True)
+            exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+            assert np.array_equal(got["bytes"], exp) and np.array_equal(got["xxh3"], exp_h)
+            for i in rng.choice(len(batch), size=200, replace=False):
+                _, st, idx = seqsets.expected(O, batch[int(i)])
+                assert int(got["strand"][i]) == st and (not batch[int(i)] or int(got["index"][i]) == idx), int(i)
+            lean = ctx.canonicalize_batch(data, offs, want_bytes=True)
+            assert np.array_equal(lean["bytes"], exp)
+        ctx.close()
+    finally:
+        del os.environ["CIRCKIT_HOST_BATCH_PARTS"]
