@@ -393,7 +393,7 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
     const uint64_t payload_end = a.offsets[a.n_records];
     uint32_t passed_on = 0, walked = 0;
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
-        if (threadIdx.x == 0) { blk_count[0] = 0; blk_count[1] = 0; }
+        if (threadIdx.x == 0) { blk_count[0] = 0; }
         __syncthreads();
         ck::canon_mixed_segment<NM, HASH>(a, slice, lut, st, blk_count, sgm, wib, 4, payload_end, htab);
         __syncthreads();
