@@ -43,7 +43,7 @@ CK_DEV uint32_t lean_window(const uint32_t* E, int32_t s) { return funnel(E[s >>
 // hold the neighbours' bytes: a stranger there sends the record to stage A for nothing, which is harmless).
 // NM: N is packed as G and its record position appended to the wave's N LIST (nl: 16-bit entries, nl_cap of them, the
 // counter *nl_count zeroed by the caller) -- with N at 1 % that is a 50th of a bitmask's LDS, so a record of config 4's
-// 20 kb still fits a slice of seven workgroups per CU; what the list cannot hold is stage A's (its mode keeps a bitmask).
+// 20 kb still fits the slice of a CU that holds six workgroups; what the list cannot hold is stage A's (its mode keeps a bitmask).
 // Nothing of the routine's scans ever looks at the list: it is read at the winning window and behind the output.
 template <bool NM>
 CK_DEV bool lean_build(const uint8_t* base, const LeanGeom& g, uint32_t* E, uint16_t* nl, uint32_t nl_cap, uint32_t* nl_count)
@@ -503,7 +503,7 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
 
 // A record's offsets and -- if it is one of 48..1008 symbols, the register routine's -- the 16 bytes this lane packs.
 // (Fetching them while the record BEFORE is being processed -- a short record is two dependent round trips, offsets -> bytes,
-// in front of ~500 cycles of work -- was tried: nothing gained on config 4, 1.87 -> 1.89 ms; the CU's 28 waves hide it, and
+// in front of ~500 cycles of work -- was tried: nothing gained on config 4, 1.87 -> 1.89 ms; the CU's 24 waves hide it, and
 // the N build lost 9 % to the registers.)
 struct MixedNext { uint64_t off, len; u32x4 v; };
 CK_DEV MixedNext mixed_fetch(const CanonArgs& a, uint32_t rec)

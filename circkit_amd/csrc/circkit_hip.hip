@@ -368,15 +368,26 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 // consumes, whose kernel carries the general routine and the team mode.  Segment s = records [s * all_seg_cap, (s + 1) *
 // all_seg_cap).  NM: the build for batches whose mode carries MODE_ALPHA (N packed as G + a mask bit per symbol).
 // Batches that also want the XXH3, the rotation index or the strand keep the rescue pass + stage A.
-// amdgpu_num_vgpr(36): on gfx90a+ the attribute counts in the unified VGPR + AGPR file at twice the value -- 72 registers,
-// seven waves per SIMD, as __launch_bounds__(256, 7) would give, but WITHOUT that bound's cut of the scalar registers to 94
-// (the trap handler's 16 are taken off 800 / 7 before rounding down): 102 are addressable at that occupancy.
+// amdgpu_num_vgpr(36): on gfx90a+ the attribute counts in the unified VGPR + AGPR file at twice the value -- 72 registers --
+// and, unlike __launch_bounds__(256, 7), leaves the kernel all 102 scalar registers.  What the CU then holds is SIX of these
+// workgroups, not seven: 106 SGPRs + the trap handler's 16 round to 128 of the SIMD's 800 (tools/probe_timeline.py stamps
+// every workgroup: exactly 6 resident per CU; 7 with CK_MIXED_WAVES=7 = 94 SGPRs and 19 spills, 8 with =8 = 78 and 32).
+// Measured on one box: 1.85 ms at six, 1.86 at seven, 1.98 at eight (smaller slices: more records for stage A) -- the
+// kernel is bound by what a CU issues and moves per cycle, not by latency; the fewest spills win.
+#ifdef CK_MIXED_TIMELINE
+// Experiment builds only (tools/probe_timeline.py): start / end of every workgroup of the last mixed-length kernel on the
+// 100 MHz wall clock, and the CU it ran on.
+__device__ uint64_t g_timeline[3 * 65536];
+#endif
 template <bool NM, bool HASH>
 __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out, uint32_t* tiers_busy)
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if ((mode & 3) != 3 || ((mode & MODE_ALPHA) != 0) != NM) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;
+#ifdef CK_MIXED_TIMELINE
+    const uint64_t tl_start = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + 4 * a.slice_dw;
     uint32_t* lut = blk_count + 4;
@@ -400,6 +411,16 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
         if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
     }
     if (threadIdx.x == 0 && passed_on > walked) *tiers_busy = 1;
+#ifdef CK_MIXED_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_timeline[3 * blockIdx.x] = tl_start; g_timeline[3 * blockIdx.x + 1] = wall_clock64();
+        g_timeline[3 * blockIdx.x + 2] = ((uint64_t)xcc << 32) | hwid;
+    }
+#endif
 }
 #ifndef CK_MIXED_NM_VGPR
 #define CK_MIXED_NM_VGPR 36
@@ -408,10 +429,15 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
 #define CK_MIXED_H_VGPR 40       // the builds with the fused XXH3: 80 registers, six waves per SIMD
 #endif
 #ifndef CK_MIXED_N_SLICE
-#define CK_MIXED_N_SLICE 1596     // dwords per wave of canon_mixed_n_kernel: six workgroups per CU (measured: 1368 = seven workgroups 2.38 ms, 1596 2.33 -- the N list of a 20 kb record needs the room)
+#define CK_MIXED_N_SLICE 1596     // dwords per wave of canon_mixed_n_kernel: six workgroups per CU by LDS as by SGPRs (measured: 1368 dwords 2.38 ms, 1596 2.33 -- the N list of a 20 kb record needs the room)
+#endif
+#ifdef CK_MIXED_WAVES
+#define CK_MIXED_ATTR(VGPR) __launch_bounds__(256, CK_MIXED_WAVES)
+#else
+#define CK_MIXED_ATTR(VGPR) __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VGPR)))
 #endif
 #define CK_MIXED_KERNEL(NAME, NM, HASH, VGPR)                                                                                                  \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VGPR))) void NAME(ck::CanonArgs a, const uint32_t* __restrict__ mode_word,   \
+    __global__ CK_MIXED_ATTR(VGPR) void NAME(ck::CanonArgs a, const uint32_t* __restrict__ mode_word,   \
                                                                                      uint32_t host_mode, uint32_t* mode_out, uint32_t* tiers_busy) \
     {                                                                                                                                          \
         canon_mixed_body<NM, HASH>(a, mode_word, host_mode, mode_out, tiers_busy);                                                             \
@@ -857,7 +883,7 @@ __global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t s
 #endif
 // A 2-bit record is admitted by its one stored strand alone, (n + 15) / 16 + 2 dwords (the candidate bitmask is only needed
 // on a tie of the minimal key; a record that ties without room for it moves on).  Tier A: 5 KiB per wave = records up to
-// 20.4 kb -- all of BASELINE config 4 in the four-wave tier, 7 workgroups = 28 waves per CU by LDS and by VGPRs alike
+// 20.4 kb -- all of BASELINE config 4 in the four-wave tier, 7 workgroups = 28 waves per CU by LDS and by VGPRs alike (6 by SGPRs for the mixed-length kernels, see there)
 // (measured on config 4, one box: A = 4 KiB + B1 = 7.4 KiB with the bitmask counted in 2.41 ms, without it 2.30,
 // A = 2.5 KiB + B1 = 5 KiB 2.41, A = 5 KiB 2.20, A = 5.5 KiB 2.47).
 #ifndef CK_TIER_A
@@ -1893,6 +1919,17 @@ int circkit_bench_copy_device(circkit_ctx* c, const void* d_src, void* d_dst, ui
     CK_HIP(c, hipGetLastError());
     return CIRCKIT_OK;
 }
+
+#ifdef CK_MIXED_TIMELINE
+int circkit_debug_timeline(circkit_ctx* c, uint64_t* host, uint32_t n_wg)
+{
+    if (!c || !host || n_wg > 65536) return CIRCKIT_ERR_INVALID_ARG;
+    CK_HIP(c, hipSetDevice(c->device));
+    CK_HIP(c, hipStreamSynchronize(c->stream));
+    CK_HIP(c, hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), (size_t)n_wg * 24));
+    return CIRCKIT_OK;
+}
+#endif
 
 #ifdef CK_DEBUG_POISON
 // Test build only (tests/poison.py; not in include/circkit.h): records of all batches since ctx creation whose staged chunk was
