@@ -686,6 +686,9 @@ int main(int argc, char** argv)
         }
         { std::lock_guard<std::mutex> g(P.m); P.n_chunks = seq; }
         P.cv.notify_all();
+        // (Handing the slots' page-locked buffers back from here while the last chunks drain -- unpinning the ring's 768 MB is
+        // 0.12 s of the process's exit -- was measured: hipHostFree waits for the device and holds up the copies still queued;
+        // the pipeline's tail grew by more than the exit shrank, 0.97-1.03 -> 1.16-1.23 s wall into /dev/null.)
     });
 
     // ---- stage 2: parsers (FASTA record boundaries + needletail normalize + CSR pack), any order
@@ -895,12 +898,32 @@ int main(int argc, char** argv)
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(),
                 init_s, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() - init_s,
                 g_read.s(), g_parse.s(), n_parsers, g_gpu.s(), g_write.s(), g_emit.s(), n_emit, g_pwrite.s());
+    const auto t_close = std::chrono::steady_clock::now();
     close_output(out);
     if (table) fclose(table);
+    const auto t_closed = std::chrono::steady_clock::now();
     close_input(in);
+    if (getenv("CIRCKIT_CLI_TIMING"))
+        fprintf(stderr, "    close output %.3f s, unmap input %.3f s\n", std::chrono::duration<double>(t_closed - t_close).count(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_closed).count());
     // Everything is written and closed.  Tearing down 768 MB of pinned buffers, the input mapping and the HIP runtime
     // takes another 0.3-0.6 s that produces nothing: leave it to the kernel (CIRCKIT_CLI_CLEAN_EXIT=1 keeps the orderly
     // teardown, e.g. under a leak checker).
+    if (getenv("CIRCKIT_CLI_TIMING") && getenv("CIRCKIT_CLI_TIMING")[0] == '2') {      // what the teardown is made of
+        auto lap = [t = std::chrono::steady_clock::now()](const char* what) mutable {
+            const auto n = std::chrono::steady_clock::now();
+            fprintf(stderr, "    teardown: %s %.3f s\n", what, std::chrono::duration<double>(n - t).count());
+            t = n;
+        };
+        if (in.map) { munmap((void*)in.map, in.map_len); lap("unmap input"); }
+        for (Slot& sl : P.slot) { sl.obuf = std::vector<uint8_t>(); }
+        lap("free assembled chunks");
+        for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }
+        lap("free pinned buffers");
+        circkit_ctx_destroy(ctx);
+        lap("ctx destroy");
+        fflush(nullptr); _exit(0);
+    }
     if (!getenv("CIRCKIT_CLI_CLEAN_EXIT")) { fflush(nullptr); _exit(0); }
     for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }   // pinned memory goes before the ctx
     circkit_ctx_destroy(ctx);

@@ -19,7 +19,7 @@ run() {   # label, command...
   label=$1; shift
   s=$(date +%s.%N); CIRCKIT_CLI_TIMING=1 "$@" 2> /tmp/cli_timing.txt; e=$(date +%s.%N)
   python3 -c "print('%-34s %.3f s wall -> %.2f M records/s' % ('$label', $e - $s, $N / ($e - $s) / 1e6))"
-  grep "busy" /tmp/cli_timing.txt | sed 's/^/    /'
+  grep "busy\|close output" /tmp/cli_timing.txt | sed "s/^/    /"
 }
 for rep in 1 2; do
   rm -f /dev/shm/out.fasta
