@@ -476,9 +476,10 @@ struct Slot {
 };
 
 struct Pipeline {
-    static constexpr int K = 6;                 // chunk slots in flight
-    static constexpr size_t CHUNK = 64u << 20;  // text bytes per chunk (one GPU batch)
-    Slot slot[K];
+    static constexpr int MAX_K = 32;
+    static int K;                               // chunk slots in flight
+    static size_t CHUNK;                        // text bytes per chunk (one GPU batch)
+    Slot slot[MAX_K];
     std::mutex m;
     std::condition_variable cv;
     long n_chunks = -1;                         // set by the reader at EOF
@@ -502,6 +503,9 @@ struct Pipeline {
     }
 };
 
+
+int Pipeline::K = 6;
+size_t Pipeline::CHUNK = 64u << 20;
 
 // rotate / cat / decat (src/rotate.rs:9-50, src/concatenate.rs:10-54): per-record byte copies of full_seq() -- the
 // sequence lines joined, nothing normalized -- done on the host; there is nothing for a GPU to win on a memcpy that
@@ -615,6 +619,8 @@ int main(int argc, char** argv)
     int n_parsers = opt.threads > 0 ? opt.threads : default_threads();   // src/commands.rs:120-123
     if (n_parsers < 1) n_parsers = 1;
     if (n_parsers > 64) n_parsers = 64;          // (beyond that the six chunk slots in flight are the limit, not the threads)
+    if (getenv("CIRCKIT_CLI_SLOTS")) { const int k = atoi(getenv("CIRCKIT_CLI_SLOTS")); if (k >= 2 && k <= Pipeline::MAX_K) Pipeline::K = k; }
+    if (getenv("CIRCKIT_CLI_CHUNK_MB")) { const int m = atoi(getenv("CIRCKIT_CLI_CHUNK_MB")); if (m >= 1 && m <= 1024) Pipeline::CHUNK = (size_t)m << 20; }
     static Pipeline P;
 
     for (Slot& sl : P.slot) {

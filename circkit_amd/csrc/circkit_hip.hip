@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/circkit.h"
@@ -944,6 +945,8 @@ struct circkit_ctx {
     uint32_t* d_gscratch = nullptr; uint64_t cap_gscratch = 0;    // bytes
     uint64_t gscratch_default = 256ull << 20;
     // the previous batch's mode (1 / 2 / 3, see stream_mode): only picks which build gets the full-size grid
+    uint64_t* h_off = nullptr;           // page-locked staging for a host batch's offsets (host_batch), h_off_cap entries
+    uint64_t h_off_cap = 0;
     volatile uint32_t* h_mode = nullptr; // pinned host word the rescue kernel writes the batch's mode to (d_mode = its device address)
     uint32_t* d_mode = nullptr;
     // uniq table
@@ -1331,6 +1334,14 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     int rc = ensure_staging(c, total, n);
     if (rc) return rc;
     const bool need_bytes = out || hash;
+    static const bool dbg_t = getenv("CIRCKIT_DEBUG_TIMING") != nullptr;
+    auto dbg_t0 = std::chrono::steady_clock::now();
+    auto dbg_lap = [&](const char* what) {
+        if (!dbg_t) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "  host_batch %-18s %.3f ms\n", what, std::chrono::duration<double>(now - dbg_t0).count() * 1e3);
+        dbg_t0 = now;
+    };
     uint64_t two_word = 0, longer = 0, max_len = 0;   // the host has the offsets: it picks the streaming kernel's build
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t len = offsets[i + 1] - offsets[i];
@@ -1357,20 +1368,11 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     }
     // ...sizes the global scratch for the longest record, whatever mode it turns out to need
     if (worst_case_dw(max_len) > TIER_D_DW && (rc = ensure_gscratch(c, worst_case_dw(max_len) * 4))) return rc;
-    // ...samples the content like stream_count_kernel does (a byte outside ACGT in the first 1008 of a sampled record)
-    const uint64_t nc = n < CONTENT_SAMPLES ? n : CONTENT_SAMPLES, cstep = n / nc;
-    uint64_t bad = 0;
-    for (uint64_t k = 0; k < nc; ++k) {
-        const uint64_t o = offsets[k * cstep], len = offsets[k * cstep + 1] - o, m = len < ck::FAST_MAX_N ? len : ck::FAST_MAX_N;
-        bool b = false;
-        for (uint64_t i = 0; i < m && !b; ++i) { const uint8_t ch = bytes[o + i]; b = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'); }
-        bad += b;
-    }
-    const uint32_t host_mode = stream_mode(two_word, longer, n) | alpha_mode(bad, nc);
     // The batch goes through the device in PARTS of >= 16 MB (up to eight): part k + 1 is copied in and part k - 1 copied out --
     // on two streams of the ctx's own -- while part k's kernels run; with page-locked buffers (circkit_host_alloc) the two
     // directions of the link work at the same time.  One part = the round-2 behaviour: in, compute, out, one after the other
     // (1 GB of 1 kb records: 37.9 ms per call, 53 GB/s for both directions together).
+    dbg_lap("offset scan");
     int parts = (int)(total / (16ull << 20));
     parts = parts < 1 ? 1 : (parts > circkit_ctx::MAX_PARTS ? circkit_ctx::MAX_PARTS : parts);
     if ((uint64_t)parts > n) parts = (int)n;
@@ -1397,12 +1399,39 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     // whatever the caller has queued on the ctx stream comes first; the offsets go with the first part
     CK_HIP(c, hipEventRecord(c->ev_head, c->stream));
     CK_HIP(c, hipStreamWaitEvent(c->s_in, c->ev_head, 0));
-    CK_HIP(c, hipMemcpyAsync(c->d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->s_in));
+    // (through a page-locked copy of them: from the caller's pageable array the runtime stages the copy and the call blocks
+    // until it is through -- 0.9 ms of a 64 MB batch's 4.2)
+    if (n + 1 > c->h_off_cap) {
+        if (c->h_off) { (void)hipHostFree((void*)c->h_off); c->h_off = nullptr; c->h_off_cap = 0; }
+        const uint64_t cap = n + 1 + (n + 1) / 8 + 1024;
+        CK_HIP(c, hipHostMalloc((void**)&c->h_off, cap * 8, hipHostMallocDefault));
+        c->h_off_cap = cap;
+    }
+    memcpy(c->h_off, offsets, (n + 1) * 8);
+    CK_HIP(c, hipMemcpyAsync(c->d_off, c->h_off, (n + 1) * 8, hipMemcpyHostToDevice, c->s_in));
     for (int k = 0; k < parts; ++k) {
         const uint64_t b0 = offsets[cut[k]], b1 = offsets[cut[k + 1]];
         if (b1 > b0) CK_HIP(c, hipMemcpyAsync(c->d_in + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, c->s_in));
         CK_HIP(c, hipEventRecord(c->ev_in[k], c->s_in));
     }
+    dbg_lap("enqueue copy-in");
+    // ...and, while the first part is on its way, samples the content like stream_count_kernel does (a byte outside ACGT in
+    // the first 1008 of a sampled record) -- on an eighth of that kernel's sample: the rule asks whether a sixteenth of the
+    // records hold such a byte, and either answer gives the same output (it picks the faster build).  Up front and over all
+    // 4096 samples this loop was 1.5-2.4 ms of EVERY call, more than the 16 MB batch it was deciding about took to cross the link.
+    const uint64_t nc = n < CONTENT_SAMPLES / 8 ? n : CONTENT_SAMPLES / 8, cstep = n / nc;
+    uint64_t bad = 0;
+    {
+        static const struct Acgt { uint8_t no[256]; Acgt() { memset(no, 1, sizeof no); no['A'] = no['C'] = no['G'] = no['T'] = 0; } } acgt;
+        for (uint64_t k = 0; k < nc; ++k) {
+            const uint64_t o = offsets[k * cstep], len = offsets[k * cstep + 1] - o, m = len < ck::FAST_MAX_N ? len : ck::FAST_MAX_N;
+            uint32_t b = 0;
+            for (uint64_t i = 0; i < m; ++i) b |= acgt.no[bytes[o + i]];
+            bad += b;
+        }
+    }
+    const uint32_t host_mode = stream_mode(two_word, longer, n) | alpha_mode(bad, nc);
+    dbg_lap("content sample");
     volatile uint32_t* unprocessed = c->h_mode + 4;                       // (pinned: one word per part)
     for (int k = 0; k < parts; ++k) {
         const uint64_t r0 = cut[k], nk = cut[k + 1] - r0, b0 = offsets[r0], b1 = offsets[cut[k + 1]];
@@ -1425,8 +1454,11 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
         if (strand) CK_HIP(c, hipMemcpyAsync(strand + r0, c->d_strand + r0, nk, hipMemcpyDeviceToHost, c->s_out));
         if (hash) CK_HIP(c, hipMemcpyAsync(hash + r0, c->d_hash + r0, nk * 8, hipMemcpyDeviceToHost, c->s_out));
     }
+    dbg_lap("enqueue parts");
     CK_HIP(c, hipStreamSynchronize(c->s_out));
+    dbg_lap("sync copy-out");
     CK_HIP(c, hipStreamSynchronize(c->stream));
+    dbg_lap("sync stream");
     uint32_t lost = 0;
     for (int k = 0; k < parts; ++k) lost += unprocessed[k];
     if (lost) return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) could not be processed", lost);
@@ -1495,6 +1527,7 @@ int circkit_ctx_destroy(circkit_ctx* c)
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     if (c->h_mode) (void)hipHostFree((void*)c->h_mode);
+    if (c->h_off) (void)hipHostFree((void*)c->h_off);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return CIRCKIT_OK;
