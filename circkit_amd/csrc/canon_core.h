@@ -49,6 +49,9 @@ struct CanonArgs {
     const uint32_t* list_count;  // [in_nseg] entries per input segment
     uint32_t in_nseg, in_seg_cap, segs_per_block;   // workgroup b consumes input segments [b*k, b*k + k), k = segs_per_block
     uint32_t all_seg_cap;        // stages that walk ALL records of a batch (mode 3): segment s = records [s * all_seg_cap, (s + 1) * all_seg_cap)
+    // ...tapered at the end (seg_records): from segment taper_seg0 on three generations of 2^taper_log2 segments hold a half,
+    // a quarter and an eighth of all_seg_cap records each (the third takes every segment behind it).  taper_log2 == 0: none.
+    uint32_t taper_seg0, taper_log2;
     uint32_t* defer_list;        // nullable: output list, one segment per workgroup of THIS launch
     uint32_t* defer_count;       // [gridDim.x]
     uint32_t out_seg_cap;
@@ -57,6 +60,24 @@ struct CanonArgs {
     uint32_t slice_dw;           // LDS dwords available to one wave
     uint32_t flags;              // CK_FLAG_*
 };
+// Records of segment s for the stages that walk all records of a batch.  Workgroups are dispatched in segment order and a
+// kernel ends when its LAST workgroup does: with equal segments the chip drains for one segment's duration (config 4: 32 768
+// segments of ~80 us, 65 us = 3.6 % of the kernel with fewer and fewer CUs at work).  The last segments are therefore smaller,
+// generation by generation, so that whatever is still running when the list runs out is short.
+CK_DEV void seg_records(const CanonArgs& a, uint32_t s, uint64_t& first, uint32_t& count)
+{
+    uint64_t f = (uint64_t)s * a.all_seg_cap;
+    uint32_t cap = a.all_seg_cap;
+    if (a.taper_log2 != 0 && s >= a.taper_seg0) {
+        const uint32_t k = (s - a.taper_seg0) >> a.taper_log2, g = k < 2 ? k : 2;
+        f = (uint64_t)a.taper_seg0 * a.all_seg_cap;
+        for (uint32_t j = 0; j < g; ++j) f += (uint64_t)(a.all_seg_cap >> (j + 1)) << a.taper_log2;
+        cap = a.all_seg_cap >> (g + 1);
+        f += (uint64_t)(s - a.taper_seg0 - (g << a.taper_log2)) * cap;
+    }
+    first = f;
+    count = (uint32_t)(f >= a.n_records ? 0 : (a.n_records - f < cap ? a.n_records - f : cap));
+}
 constexpr uint32_t CK_FLAG_FWD_ONLY = 1u;   // lmsr(): forward strand only (lib/src/canonicalize.rs:41-47)
 
 

@@ -576,13 +576,14 @@ CK_DEV bool mixed_short_n(const CanonArgs& a, const uint32_t* lut, RescueState<H
     return done;
 }
 
-// One wave's share of segment `sgm` of a mode-3 batch: records [sgm * all_seg_cap, ...), every wpb-th from wib on.
+// One wave's share of segment `sgm` of a mode-3 batch (seg_records), every wpb-th record from wib on.
 template <bool NM, bool HASH = false>
 CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint32_t* lut, RescueState<HASH, false>& st,
                                 uint32_t* blk_count, uint32_t sgm, uint32_t wib, uint32_t wpb, uint64_t payload_end, const uint32_t* htab = nullptr)
 {
-    const uint64_t first = (uint64_t)sgm * a.all_seg_cap;
-    const uint32_t count = (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap));
+    uint64_t first;
+    uint32_t count;
+    seg_records(a, sgm, first, count);
     // (handing the records out one at a time through an LDS counter, so that no wave waits for the one that drew the long
     // records, measured slower: 1.86 -> 1.91 ms)
     for (uint32_t i = wib; i < count; i += wpb) {

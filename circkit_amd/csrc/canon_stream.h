@@ -354,9 +354,10 @@ CK_DEV void canon_rescue_segment(const CanonArgs& a, const uint32_t* lut, Rescue
                                  uint32_t wib, uint32_t wpb, bool all_records)
 {
     const uint32_t t = lane_id();
-    const uint64_t first = (uint64_t)seg_index * a.all_seg_cap;          // (all_records only)
-    const uint32_t count = all_records ? (uint32_t)(first >= a.n_records ? 0 : (a.n_records - first < a.all_seg_cap ? a.n_records - first : a.all_seg_cap))
-                                       : a.list_count[seg_index];
+    uint64_t first = 0;                                                   // (all_records only)
+    uint32_t count;
+    if (all_records) seg_records(a, seg_index, first, count);
+    else count = a.list_count[seg_index];
     const uint32_t* seg = a.list + (uint64_t)seg_index * a.in_seg_cap;
     if constexpr (!ALPHA) {
         // the lean build: one record at a time, pure-ACGT records only (what is left after the streaming kernel of an

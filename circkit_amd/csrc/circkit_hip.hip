@@ -1030,8 +1030,20 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     // segment is one workgroup of every stage behind -- 2000 records of 250 kb in 125 segments of 16 left half the chip idle.
     const unsigned G_small = (unsigned)(n < (uint64_t)N_CU * 16 ? n : (uint64_t)N_CU * 16);
     if (G < G_small) G = G_small;
-    const uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see
-    const uint32_t all_cap = (uint32_t)((n + G - 1) / G);
+    uint32_t cap = (uint32_t)(per_step * ((blocks + G - 1) / G));     // records one workgroup can see = entries of a list segment
+    uint32_t all_cap = (uint32_t)((n + G - 1) / G);
+    // the walking stages' segments taper off at the end (canon_core.h seg_records): three generations of G/16 segments with
+    // a half, a quarter, an eighth of the records of the ones before
+    uint32_t taper_seg0 = 0, taper_log2 = 0;
+#ifndef CK_NO_TAPER
+    if (G >= 4096 && all_cap >= 16) {
+        while ((2u << taper_log2) <= G / 16) ++taper_log2;
+        const uint64_t gen = 1ull << taper_log2;
+        taper_seg0 = G - (uint32_t)(3 * gen);
+        while ((uint64_t)taper_seg0 * all_cap + gen * ((all_cap >> 1) + (all_cap >> 2) + (all_cap >> 3)) < n) ++all_cap;
+        if (cap < all_cap) cap = all_cap;
+    }
+#endif
     // + 1024 segments of slack: a stage that merges k segments per workgroup addresses up to k - 1 segments past the end
     int rc = ensure_lists(c, (uint64_t)G * cap + 1024ull * cap, G < 256u ? 256u : G);
     if (rc) return rc;
@@ -1067,7 +1079,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     a.out_bytes = d_out; a.out_index = d_idx; a.out_strand = d_strand; a.out_hash = d_hash; a.hashed = c->d_hashed; a.out_view = view;
     a.comp_lut = c->d_comp; a.status = c->d_counters + 3; a.flags = flags;
     // streaming kernel over every record; what it cannot take goes down the LDS tiers
-    a.list = nullptr; a.list_count = nullptr; a.all_seg_cap = all_cap;
+    a.list = nullptr; a.list_count = nullptr; a.all_seg_cap = all_cap; a.taper_seg0 = taper_seg0; a.taper_log2 = taper_log2;
     a.defer_list = c->d_lists[0]; a.defer_count = c->d_seg_counts; a.out_seg_cap = cap;
     a.slice_dw = 0;
     const uint32_t* counts = c->d_counters + 5;     // the mode word

@@ -311,3 +311,23 @@ extern "C" uint64_t emu_xxh3_64(const uint8_t* p, uint32_t n)
         if (H.out[i] != H.out[0]) { fprintf(stderr, "emu: xxh3 lanes disagree\n"); abort(); }
     return H.out[0];
 }
+
+// seg_records (canon_core.h): the segments of a walking stage must tile [0, n) exactly once, in order.  Returns the number of
+// segments that hold records, or -1 at the first gap / overlap / oversized segment.
+extern "C" int64_t emu_seg_cover(uint64_t n, uint32_t nseg, uint32_t all_cap, uint32_t taper_seg0, uint32_t taper_log2)
+{
+    ck::CanonArgs a{};
+    a.n_records = n; a.all_seg_cap = all_cap; a.taper_seg0 = taper_seg0; a.taper_log2 = taper_log2;
+    uint64_t next = 0;
+    int64_t used = 0;
+    for (uint32_t s = 0; s < nseg; ++s) {
+        uint64_t first; uint32_t count;
+        ck::seg_records(a, s, first, count);
+        if (count > all_cap) return -1;
+        if (count == 0) continue;
+        if (first != next) return -1;
+        next = first + count;
+        ++used;
+    }
+    return next == n ? used : -1;
+}

@@ -745,3 +745,37 @@ def test_mixed_kernel_with_fused_xxh3(with_n, hash_only):
         assert (out == 0x3F).all()
     if not with_n:
         assert emu.last_fused_hash_count >= 60                           # the long pure records' hashes are the lean routine's own
+
+
+def _host_taper(n, G):
+    """launch_canon's sizing of the walking stages' segments (circkit_hip.hip): (all_cap, taper_seg0, taper_log2)."""
+    all_cap = -(-n // G)
+    seg0 = log2 = 0
+    if G >= 4096 and all_cap >= 16:
+        while (2 << log2) <= G // 16:
+            log2 += 1
+        gen = 1 << log2
+        seg0 = G - 3 * gen
+        while seg0 * all_cap + gen * ((all_cap >> 1) + (all_cap >> 2) + (all_cap >> 3)) < n:
+            all_cap += 1
+    return all_cap, seg0, log2
+
+
+def test_tapered_segments_tile_the_batch():
+    """seg_records: equal segments, then three generations of smaller ones -- every record in exactly one segment."""
+    import ctypes
+    lib = ctypes.CDLL(emu.build())
+    lib.emu_seg_cover.restype = ctypes.c_int64
+    lib.emu_seg_cover.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    cases = [(1_000_000, 32768), (10_000_000, 32768), (999_983, 32768), (70_000, 4096), (65_536, 4096), (131_071, 8191),
+             (5_000_000, 20_000), (524_288, 32768), (524_289, 32768), (100, 100), (50_000, 4095)]
+    for n, G in cases:
+        cap, seg0, log2 = _host_taper(n, G)
+        used = lib.emu_seg_cover(n, G, cap, seg0, log2)
+        assert used > 0, (n, G, cap, seg0, log2)
+        if log2:
+            gen = 1 << log2
+            assert seg0 + 3 * gen == G and cap >> 3 >= 1
+    # no taper = the plain mapping
+    assert lib.emu_seg_cover(1000, 10, 100, 0, 0) == 10
+    assert lib.emu_seg_cover(1001, 10, 100, 0, 0) == -1
