@@ -945,7 +945,7 @@ struct circkit_ctx {
     uint32_t* d_gscratch = nullptr; uint64_t cap_gscratch = 0;    // bytes
     uint64_t gscratch_default = 256ull << 20;
     // the previous batch's mode (1 / 2 / 3, see stream_mode): only picks which build gets the full-size grid
-    uint64_t* h_off = nullptr;           // page-locked staging for a host batch's offsets (host_batch), h_off_cap entries
+    uint64_t* h_off = nullptr;           // page-locked staging of a host batch's offsets and per-record outputs (host_batch): h_off_cap x (8 + 8 + 4 + 1) bytes
     uint64_t h_off_cap = 0;
     volatile uint32_t* h_mode = nullptr; // pinned host word the rescue kernel writes the batch's mode to (d_mode = its device address)
     uint32_t* d_mode = nullptr;
@@ -1380,18 +1380,36 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     }
     // ...sizes the global scratch for the longest record, whatever mode it turns out to need
     if (worst_case_dw(max_len) > TIER_D_DW && (rc = ensure_gscratch(c, worst_case_dw(max_len) * 4))) return rc;
-    // The batch goes through the device in PARTS of >= 16 MB (up to eight): part k + 1 is copied in and part k - 1 copied out --
-    // on two streams of the ctx's own -- while part k's kernels run; with page-locked buffers (circkit_host_alloc) the two
-    // directions of the link work at the same time.  One part = the round-2 behaviour: in, compute, out, one after the other
+    // The batch goes through the device in PARTS of >= 16 MB (up to eight): part k + 1 is copied in while part k - 1 is copied
+    // out on a stream of the ctx's own; with page-locked buffers (circkit_host_alloc) the two directions of the link work at
+    // the same time.  One part = the round-2 behaviour: in, compute, out, one after the other
     // (1 GB of 1 kb records: 37.9 ms per call, 53 GB/s for both directions together).
     dbg_lap("offset scan");
     int parts = (int)(total / (16ull << 20));
     parts = parts < 1 ? 1 : (parts > circkit_ctx::MAX_PARTS ? circkit_ctx::MAX_PARTS : parts);
     if ((uint64_t)parts > n) parts = (int)n;
     if (getenv("CIRCKIT_HOST_BATCH_PARTS")) { const int p = atoi(getenv("CIRCKIT_HOST_BATCH_PARTS")); if (p >= 1 && p <= circkit_ctx::MAX_PARTS && (uint64_t)p <= n) parts = p; }
-    if (!c->s_in) {
-        CK_HIP(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
-        CK_HIP(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    // The copy-in rides the ctx stream itself, part k + 1 queued behind part k's kernels (a few hundred microseconds next to the
+    // milliseconds of a part's copy); the copy-out has a stream of the ctx's own, at a priority of its own (the runtime keeps
+    // a separate set of hardware queues per priority: no queue shared with the ctx stream or any default-priority stream).
+    // With a plain copy-in and a plain copy-out stream -- round 3's first arrangement -- the two directions of a call
+    // overlapped or took turns (1 GB: 24.8 or 38-40 ms) depending on how many streams the process had made before: one extra
+    // stream ahead of the ctx was slow in 2 runs of 2 (tools/probe_stream_luck.py), and so were bench.py's `uniq` processes.
+    // In this arrangement 130 fresh processes in the same probes were fast but one (40 ms, not reproduced: 72 of 72 in the
+    // same configuration afterwards, tools/probe_duplex_rate.sh).  Moving the bytes out by a copy kernel that stores across
+    // the link instead of the DMA engine: 28 ms, and it took turns as well when it did.
+    // CIRCKIT_HOST_BATCH_PLAIN_STREAMS=1: the first arrangement, for comparison.
+    static const bool plain_streams = getenv("CIRCKIT_HOST_BATCH_PLAIN_STREAMS") != nullptr;
+    const bool inline_h2d = !plain_streams;
+    if (!c->s_out) {
+        if (plain_streams) {
+            CK_HIP(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+            CK_HIP(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        } else {
+            int prio_least = 0, prio_greatest = 0;
+            CK_HIP(c, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+            CK_HIP(c, hipStreamCreateWithPriority(&c->s_out, hipStreamNonBlocking, prio_greatest));
+        }
         CK_HIP(c, hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming));
         for (int k = 0; k < circkit_ctx::MAX_PARTS; ++k) {
             CK_HIP(c, hipEventCreateWithFlags(&c->ev_in[k], hipEventDisableTiming));
@@ -1410,22 +1428,31 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     }
     // whatever the caller has queued on the ctx stream comes first; the offsets go with the first part
     CK_HIP(c, hipEventRecord(c->ev_head, c->stream));
-    CK_HIP(c, hipStreamWaitEvent(c->s_in, c->ev_head, 0));
+    if (!inline_h2d) CK_HIP(c, hipStreamWaitEvent(c->s_in, c->ev_head, 0));
     // (through a page-locked copy of them: from the caller's pageable array the runtime stages the copy and the call blocks
     // until it is through -- 0.9 ms of a 64 MB batch's 4.2)
+    // The per-record outputs (hash, index, strand: 13 bytes a record) come back the same way: into page-locked staging part by
+    // part, to the caller's arrays once at the end -- a copy-out to pageable memory would hold up every part behind it
+    // (uniq on 1M x 1 kb: 38.6 ms per call with the hashes going straight to a pageable array, 23.7 without hashes).
     if (n + 1 > c->h_off_cap) {
         if (c->h_off) { (void)hipHostFree((void*)c->h_off); c->h_off = nullptr; c->h_off_cap = 0; }
         const uint64_t cap = n + 1 + (n + 1) / 8 + 1024;
-        CK_HIP(c, hipHostMalloc((void**)&c->h_off, cap * 8, hipHostMallocDefault));
+        CK_HIP(c, hipHostMalloc((void**)&c->h_off, cap * (8 + 8 + 4 + 1), hipHostMallocDefault));
         c->h_off_cap = cap;
     }
+    uint64_t* const st_hash = c->h_off + c->h_off_cap;
+    uint32_t* const st_idx = (uint32_t*)(st_hash + c->h_off_cap);
+    uint8_t* const st_strand = (uint8_t*)(st_idx + c->h_off_cap);
     memcpy(c->h_off, offsets, (n + 1) * 8);
-    CK_HIP(c, hipMemcpyAsync(c->d_off, c->h_off, (n + 1) * 8, hipMemcpyHostToDevice, c->s_in));
-    for (int k = 0; k < parts; ++k) {
+    hipStream_t sin = inline_h2d ? c->stream : c->s_in;
+    CK_HIP(c, hipMemcpyAsync(c->d_off, c->h_off, (n + 1) * 8, hipMemcpyHostToDevice, sin));
+    auto copy_in = [&](int k) -> int {
         const uint64_t b0 = offsets[cut[k]], b1 = offsets[cut[k + 1]];
-        if (b1 > b0) CK_HIP(c, hipMemcpyAsync(c->d_in + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, c->s_in));
-        CK_HIP(c, hipEventRecord(c->ev_in[k], c->s_in));
-    }
+        if (b1 > b0) CK_HIP(c, hipMemcpyAsync(c->d_in + b0, bytes + b0, b1 - b0, hipMemcpyHostToDevice, sin));
+        if (!inline_h2d) CK_HIP(c, hipEventRecord(c->ev_in[k], sin));
+        return CIRCKIT_OK;
+    };
+    for (int k = 0; k < (inline_h2d ? 1 : parts); ++k) if ((rc = copy_in(k))) return rc;
     dbg_lap("enqueue copy-in");
     // ...and, while the first part is on its way, samples the content like stream_count_kernel does (a byte outside ACGT in
     // the first 1008 of a sampled record) -- on an eighth of that kernel's sample: the rule asks whether a sixteenth of the
@@ -1447,12 +1474,13 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     volatile uint32_t* unprocessed = c->h_mode + 4;                       // (pinned: one word per part)
     for (int k = 0; k < parts; ++k) {
         const uint64_t r0 = cut[k], nk = cut[k + 1] - r0, b0 = offsets[r0], b1 = offsets[cut[k + 1]];
-        CK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in[k], 0));
+        if (!inline_h2d) CK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in[k], 0));
         rc = launch_canon(c, c->d_in, c->d_off + r0, nk, need_bytes ? c->d_out : nullptr, idx ? c->d_idx + r0 : nullptr,
                           strand ? c->d_strand + r0 : nullptr, hash ? c->d_hash + r0 : nullptr, flags, host_mode);
-        if (rc) { (void)hipStreamSynchronize(c->s_in); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); return rc; }
+        if (rc) { if (c->s_in) (void)hipStreamSynchronize(c->s_in); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); return rc; }
         CK_HIP(c, hipEventRecord(c->ev_done[k], c->stream));
         CK_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_done[k], 0));
+        if (inline_h2d && k + 1 < parts && (rc = copy_in(k + 1))) return rc;
         // the part's count of records nothing could take first: the next part's launch zeroes the counter again and waits for
         // this copy of it (and for nothing else of the copy-out)
         unprocessed[k] = 0;
@@ -1462,15 +1490,18 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
             CK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_head, 0));
         }
         if (out && b1 > b0) CK_HIP(c, hipMemcpyAsync(out + b0, c->d_out + b0, b1 - b0, hipMemcpyDeviceToHost, c->s_out));
-        if (idx) CK_HIP(c, hipMemcpyAsync(idx + r0, c->d_idx + r0, nk * 4, hipMemcpyDeviceToHost, c->s_out));
-        if (strand) CK_HIP(c, hipMemcpyAsync(strand + r0, c->d_strand + r0, nk, hipMemcpyDeviceToHost, c->s_out));
-        if (hash) CK_HIP(c, hipMemcpyAsync(hash + r0, c->d_hash + r0, nk * 8, hipMemcpyDeviceToHost, c->s_out));
+        if (idx) CK_HIP(c, hipMemcpyAsync(st_idx + r0, c->d_idx + r0, nk * 4, hipMemcpyDeviceToHost, c->s_out));
+        if (strand) CK_HIP(c, hipMemcpyAsync(st_strand + r0, c->d_strand + r0, nk, hipMemcpyDeviceToHost, c->s_out));
+        if (hash) CK_HIP(c, hipMemcpyAsync(st_hash + r0, c->d_hash + r0, nk * 8, hipMemcpyDeviceToHost, c->s_out));
     }
     dbg_lap("enqueue parts");
     CK_HIP(c, hipStreamSynchronize(c->s_out));
     dbg_lap("sync copy-out");
     CK_HIP(c, hipStreamSynchronize(c->stream));
     dbg_lap("sync stream");
+    if (idx) memcpy(idx, st_idx, n * 4);
+    if (strand) memcpy(strand, st_strand, n);
+    if (hash) memcpy(hash, st_hash, n * 8);
     uint32_t lost = 0;
     for (int k = 0; k < parts; ++k) lost += unprocessed[k];
     if (lost) return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) could not be processed", lost);

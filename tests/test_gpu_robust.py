@@ -142,3 +142,40 @@ def test_host_batch_in_parts(O, parts):
         ctx.close()
     finally:
         del os.environ["CIRCKIT_HOST_BATCH_PARTS"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 16, 5])
+def test_host_batch_page_locked_output(O, shift):
+    """Page-locked input and output buffers (circkit_host_alloc), five parts: the copy-in rides the ctx stream between the
+    parts' kernels, the copy-out runs on the ctx's priority stream at the same time -- same bytes as the oracle's, at any
+    alignment of the output pointer and of the part boundaries, and nothing written outside the payload."""
+    import ctypes
+    import circkit_amd
+    from tests import seqsets
+    os.environ["CIRCKIT_HOST_BATCH_PARTS"] = "5"
+    try:
+        ctx = circkit_amd.Context(0)
+        lib = circkit_amd.load_library()
+        seqs = seqsets.random_mixed(910, 900, 900, 1008) + seqsets.random_mixed(911, 80, 1009, 9000) + seqsets.random_mixed(912, 200, 1, 333) + [b"", b"ACGTA" * 777]
+        data, offs = seqsets.pack(seqs)
+        nb = len(data)
+        exp, _ = O.canonicalize_batch(data, offs, True, False, threads=8)
+        pin_in, pin_out = lib.circkit_host_alloc(nb + 64), lib.circkit_host_alloc(nb + 64 + 32)
+        assert pin_in and pin_out
+        try:
+            ctypes.memmove(pin_in, data.ctypes.data, nb)
+            ctypes.memset(pin_out, 0xEE, nb + 64 + 32)
+            offs64 = np.ascontiguousarray(offs, dtype=np.uint64)
+            for _ in range(2):
+                rc = lib.circkit_canonicalize_batch(ctx._h, pin_in, offs64.ctypes.data, len(seqs), pin_out + shift, None, None, None)
+                assert rc == 0
+                got = np.frombuffer((ctypes.c_uint8 * (nb + 64 + 32)).from_address(pin_out), dtype=np.uint8)
+                assert np.array_equal(got[shift:shift + nb], exp)
+                assert (got[:shift] == 0xEE).all() and (got[shift + nb:] == 0xEE).all()       # nothing outside the payload
+        finally:
+            lib.circkit_host_free(pin_in)
+            lib.circkit_host_free(pin_out)
+        ctx.close()
+    finally:
+        del os.environ["CIRCKIT_HOST_BATCH_PARTS"]

@@ -11,12 +11,14 @@ dev = torch.device("cuda", 0)
 ctx = circkit_amd.Context(0)
 lib = circkit_amd.load_library()
 L = 1000
+WITH_HASH = os.environ.get("PROBE_HASH") == "1"      # + the XXH3 of every record (what uniq asks for)
 for mb in (16, 64, 256, 1024):
     S = mb * (1 << 20) // L
     nb = S * L
     d_bytes, d_off = W.fixed_length(ctx, dev, S, L, 42, 0)
     torch.cuda.synchronize()
     h_off = d_off.cpu().numpy().astype(np.uint64)
+    h_hash = np.empty(S, dtype=np.uint64)
     pin_in, pin_out, pin_off = lib.circkit_host_alloc(nb + 64), lib.circkit_host_alloc(nb + 64), lib.circkit_host_alloc(8 * (S + 1))
     torch.frombuffer((ctypes.c_uint8 * nb).from_address(pin_in), dtype=torch.uint8).copy_(d_bytes[:nb])
     ctypes.memmove(pin_off, h_off.ctypes.data, 8 * (S + 1))
@@ -27,7 +29,7 @@ for mb in (16, 64, 256, 1024):
         else:
             os.environ.pop("CIRCKIT_HOST_BATCH_PARTS", None)
         def call():
-            rc = lib.circkit_canonicalize_batch(ctx._h, pin_in, off_ptr, S, pin_out, None, None, None)
+            rc = lib.circkit_canonicalize_batch(ctx._h, pin_in, off_ptr, S, pin_out, None, None, h_hash.ctypes.data if WITH_HASH else None)
             assert rc == 0, rc
         call(); call()
         reps = max(3, 512 // mb)
