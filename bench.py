@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--max-len", type=int, default=20000, help="mixed: upper end of the log-uniform lengths (BASELINE configs[3]: 20000)")
     ap.add_argument("--with-hash", action="store_true",
                     help="mixed: also the XXH3 of every record and the first-seen resolution (`circkit uniq --canonicalize` on records of mixed lengths)")
+    ap.add_argument("--hash-only", action="store_true",
+                    help="uniq / --with-hash: no canonical bytes are written (`circkit uniq` without --canonicalize, src/uniq.rs:55-60): "
+                         "XXH3 of the canonical form + first-seen only; SURVEY 8d prices this mode at L + 16 bytes per record")
     ap.add_argument("--workload", default="canonicalize", choices=["canonicalize", "uniq", "mixed"],
                     help="canonicalize = BASELINE configs[1] (the headline metric); uniq = configs[2] (50 %% rotational/"
                          "strand duplicates, hash + first-seen); mixed = configs[3] (1M records, L ~ 1/L on [200, 20000])")
@@ -177,11 +180,11 @@ def main():
             if args.workload == "uniq":
                 # what `circkit uniq --canonicalize` computes per batch: canonical bytes + XXH3, then the first-seen
                 # resolution -- the ctx table on one GPU, the hash-range exchange over RCCL on several
-                ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"], out_xxh3=ln["hash"])
+                ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=None if args.hash_only else ln["out"], out_xxh3=ln["hash"])
                 ln["fs"], ln["keep"] = U.first_seen(ln["table"], ln["hash"], base_index=rank * N, exchange=args.exchange,
                                                     force_exchange=force_dist)
             elif args.with_hash:
-                ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"], out_xxh3=ln["hash"])
+                ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=None if args.hash_only else ln["out"], out_xxh3=ln["hash"])
                 ln["fs"], ln["keep"] = U.first_seen(ln["table"], ln["hash"], base_index=rank * N, exchange=args.exchange, force_exchange=force_dist)
             else:
                 ln["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=ln["out"])
@@ -237,6 +240,8 @@ def main():
         if args.workload == "uniq" or args.with_hash:
             algo_bytes += 8 * N
             table_bytes = 32 * N
+            if args.hash_only:
+                algo_bytes = total + 16 * N           # "uniq hash-only mode (no canonical bytes written back): L + 16"
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         nvar = ", %g %% of the bases replaced by N" % (100 * args.n_frac) if args.n_frac > 0 else ""
         # the kernel chain the step really ran: which streaming build the batch's own mode picked, which table path
@@ -262,6 +267,10 @@ def main():
                 kernel = stream_build + " + all_gather + uniq_insert_kernel x%d + uniq_lookup_kernel" % world
             par = ("records sharded over %d GPU(s); first-seen resolved by one hash-range all-to-all over RCCL (exchange=%s)"
                    % (world, args.exchange)) if use_dist else "1 GPU: the ctx hash table, no collective"
+            if args.hash_only:
+                metric = metric.replace("uniq sequences/sec", "uniq (hash-only) sequences/sec")
+                wl = wl.replace("uniq --canonicalize,", "uniq without --canonicalize (no canonical bytes written: XXH3 of the canonical form + first-seen),")
+                kernel += " (+ xxh3_kernel on (rotation, strand) views for records whose hash is not fused)"
         else:
             metric = "canonicalize sequences/sec (%d records, 200b-%dkb log-uniform lengths)" % (N, args.max_len // 1000)
             wl = "canonicalize, %d records, lengths log-uniform on [200, %d], %d bases per GPU%s (%s)" % (
@@ -272,8 +281,11 @@ def main():
             if args.with_hash:
                 metric = "uniq --canonicalize sequences/sec (%d records, 200b-%dkb log-uniform lengths, all distinct)" % (N, args.max_len // 1000)
                 wl = wl.replace("canonicalize,", "canonicalize + XXH3 + first-seen,")
+                if args.hash_only:
+                    metric = metric.replace("uniq --canonicalize", "uniq (hash-only)")
+                    wl = wl.replace("canonicalize + XXH3 + first-seen,", "XXH3 of the canonical form + first-seen, no canonical bytes written,")
             par = "records sharded over %d GPU(s) by contiguous index ranges, no data-path collective" % world
-        traffic, traffic_source = pmc_traffic("%s %d x %d" % (args.workload, N, L) + (" n%g" % args.n_frac if nvar else "") + (" hash" if args.with_hash else ""))
+        traffic, traffic_source = pmc_traffic("%s %d x %d" % (args.workload, N, L) + (" n%g" % args.n_frac if nvar else "") + (" hash" if args.with_hash else "") + (" hash-only" if args.hash_only else ""))
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes}
@@ -299,6 +311,7 @@ def main():
         }
         if unique_global is not None:
             result["unique_records"] = unique_global
+        args._state_hash = state["hash"]
         if world == 1 and not args.no_e2e:
             result["end_to_end"] = end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out)
         if world == 1 and not args.no_cpu:
@@ -358,10 +371,12 @@ def end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out):
     h_in.copy_(d_bytes[first:first + nb])
     torch.cuda.synchronize()
     want_hash = args.workload == "uniq" or args.with_hash
+    hash_only = want_hash and args.hash_only
     h_hash = np.empty(S, dtype=np.uint64) if want_hash else None
+    state_hash = getattr(args, "_state_hash", None)
 
     def call():
-        rc = lib.circkit_canonicalize_batch(ctx._h, pin_in, h_off.ctypes.data, S, pin_out, None, None,
+        rc = lib.circkit_canonicalize_batch(ctx._h, pin_in, h_off.ctypes.data, S, None if hash_only else pin_out, None, None,
                                             h_hash.ctypes.data if want_hash else None)
         if rc:
             raise SystemExit("circkit_canonicalize_batch failed: %d" % rc)
@@ -371,8 +386,11 @@ def end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out):
     for _ in range(reps):
         call()
     dt = (time.perf_counter() - t0) / reps
-    got = torch.frombuffer((ctypes.c_uint8 * nb).from_address(pin_out), dtype=torch.uint8)
-    same = bool(torch.equal(got, d_out[first:first + nb].cpu()))
+    if hash_only:       # nothing came back but the hashes: they must be the device path's
+        same = state_hash is not None and bool(np.array_equal(h_hash.view(np.int64), state_hash[:S].cpu().numpy()))
+    else:
+        got = torch.frombuffer((ctypes.c_uint8 * nb).from_address(pin_out), dtype=torch.uint8)
+        same = bool(torch.equal(got, d_out[first:first + nb].cpu()))
     lib.circkit_host_free(pin_in)
     lib.circkit_host_free(pin_out)
     return {"value": S / dt, "unit": "sequences/s", "kind": "PCIe-inclusive, host-buffer API (circkit_canonicalize_batch), pinned buffers, one call after the other (inside a call: up to 8 parts, "
@@ -410,7 +428,10 @@ def cpu_baseline(args, np, torch, N, L, total, d_bytes, d_off, d_out, state):
     h_out, h_hash = O.canonicalize_batch(h_in, h_off, True, want_hash, threads=cores)
     fs = O.uniq_first_seen(h_hash) if want_hash else None          # single thread, as the reference's main-thread closure
     cdt = time.perf_counter() - c0
-    same = bool(np.array_equal(h_out, d_out[:nb].cpu().numpy()))
+    if want_hash and args.hash_only:       # no canonical bytes on the device in this mode: the hashes of the canonical forms instead
+        same = bool(np.array_equal(h_hash.view(np.int64), state["hash"][:S].cpu().numpy()))
+    else:
+        same = bool(np.array_equal(h_out, d_out[:nb].cpu().numpy()))
     if want_hash:
         # first-seen over the whole batch restricted to the first S records = first-seen of the sample alone
         same = same and bool(np.array_equal(fs.astype(np.int64), state["fs"][:S].cpu().numpy().astype(np.int64)))
