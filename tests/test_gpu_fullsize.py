@@ -233,3 +233,22 @@ def test_bench_uniq_runs_the_exchange_and_counts_globally():
     assert line["unique_records"] == 200000
     assert "RCCL" in line["config"]["parallelism"]
     assert line["cpu_baseline"]["gpu_output_matches"] is True
+
+
+@pytest.mark.parametrize("workload", [["--workload", "uniq"], ["--workload", "mixed", "--with-hash"]])
+def test_bench_hash_only_lines(workload):
+    """bench.py --hash-only (`circkit uniq` without --canonicalize: no canonical bytes are written, SURVEY 8d's L + 16 bytes per
+    record): the line prices the step on that formula, the hashes of the device path, of the host-buffer path and of the CPU
+    oracle agree, and the unique count is right."""
+    import json
+    records = "300000" if workload[1] == "uniq" else "40000"
+    out = _run([sys.executable, os.path.join(ROOT, "bench.py")] + workload + ["--hash-only", "--records", records, "--steps", "2", "--warmup", "1", "--no-copy"])
+    line = json.loads(out.strip().splitlines()[-1])
+    assert "hash-only" in line["metric"]
+    n = int(records)
+    total = line["roofline"]["algorithmic_bytes"] - 16 * n
+    assert total == (n * 1000 if workload[1] == "uniq" else total) and total > 0
+    assert line["end_to_end"]["matches_device_path"] is True
+    assert line["cpu_baseline"]["gpu_output_matches"] is True
+    if workload[1] == "uniq":
+        assert line["unique_records"] == n // 2
