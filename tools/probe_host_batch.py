@@ -38,6 +38,20 @@ for mb in (16, 64, 256, 1024):
             call()
         dt = (time.perf_counter() - t0) / reps
         print("%5d MB  %-24s %.3f ms per call = %.1f GB/s in + out" % (mb, label, dt * 1e3, 2 * nb / dt / 1e9), flush=True)
+    # pageable payload buffers (plain numpy arrays): the runtime stages every copy
+    pg_in = np.empty(nb + 64, dtype=np.uint8); pg_out = np.empty(nb + 64, dtype=np.uint8)
+    ctypes.memmove(pg_in.ctypes.data, pin_in, nb)
+    os.environ.pop("CIRCKIT_HOST_BATCH_PARTS", None)
+    def callp():
+        rc = lib.circkit_canonicalize_batch(ctx._h, pg_in.ctypes.data, h_off.ctypes.data, S, pg_out.ctypes.data, None, None, None)
+        assert rc == 0, rc
+    callp(); callp()
+    reps = max(3, 512 // mb)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        callp()
+    dt = (time.perf_counter() - t0) / reps
+    print("%5d MB  %-24s %.3f ms per call = %.1f GB/s in + out" % (mb, "pageable payload", dt * 1e3, 2 * nb / dt / 1e9), flush=True)
     for p in (pin_in, pin_out, pin_off):
         lib.circkit_host_free(p)
     del d_bytes, d_off
