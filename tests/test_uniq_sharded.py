@@ -97,17 +97,19 @@ def _worker(rank, world, port, hashes, cuts, q, exchange, rows_table=False):
 
 
 @pytest.mark.parametrize("exchange,world,rows_table", [("partition", 2, False), ("allgather", 2, False), ("partition", 3, False),
-                                                       ("partition", 2, True), ("partition", 3, True), ("partition", 4, True)])
+                                                       ("partition", 2, True), ("partition", 3, True), ("partition", 4, True),
+                                                       ("partition", 8, True), ("allgather", 8, False)])
 def test_sharded_first_seen_matches_single_process(exchange, world, rows_table):
     """Both exchange steps of circkit_amd/uniq.py -- the hash-range all-to-all (default) and the all-gather -- give
-    the single-process first-seen result, with unequal shards (one of them empty at world 3 and 4) and sign-bit hashes.
+    the single-process first-seen result, with unequal shards (one of them empty at world 3, 4 and 8) and sign-bit hashes.
     rows_table: the branch the device table takes (partition -> all_to_all -> insert_rows / lookup_rows -> all_to_all ->
     gather), with the table's kernels replaced by RowsTable."""
     from oracle import oracle as O
     rng = np.random.default_rng(3)
     n = 5000
     hashes = rng.integers(0, 1200, size=n).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)   # ~4x duplicates, top bit set in half
-    cuts = {2: [0, 1777, n], 3: [0, 1777, 1777, n], 4: [0, 5, 1777, 1777, n]}[world]          # unequal shards
+    cuts = {2: [0, 1777, n], 3: [0, 1777, 1777, n], 4: [0, 5, 1777, 1777, n],
+            8: [0, 5, 700, 700, 1777, 2500, 2501, 4100, n]}[world]          # unequal shards (8 = BASELINE config 5's world size)
     expect = O.uniq_first_seen(hashes).astype(np.int64)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
