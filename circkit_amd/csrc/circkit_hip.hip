@@ -315,7 +315,7 @@ __global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __res
 // every kernel of a batch takes the mode from the same word (or the host's answer): bits 0..1 = stream_mode, MODE_ALPHA
 __device__ __forceinline__ uint32_t batch_mode(const uint32_t* __restrict__ mode, uint32_t host_mode)
 {
-    return host_mode ? host_mode : *mode;
+    return host_mode ? host_mode & 7u : *mode;          // (bit 31: MODE_GUESS, see launch_canon)
 }
 // Rescue pass (canon_stream.h): the streaming kernel's leftovers that are eligible by themselves, one wave per record.
 // A small persistent grid walks the list segments (a batch the streaming kernel handled completely leaves them
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if (!AUX && ((mode & MODE_ALPHA) != 0) != ALPHA) return;            // the other build has this batch
     if (!AUX && (mode & 3) == 3) return;                                 // ... or a canon_mixed kernel (either alphabet, with or without the XXH3)
-    if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;          // for circkit_ctx_last_batch_mode() and the next batch's launch hint
+    if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = (host_mode >> 31) ? *mode_word : mode;     // for circkit_ctx_last_batch_mode() and the next batch's launch: the batch's OWN mode
     const bool all_records = (mode & 3) == 3;                           // the streaming kernel stood this batch out
     if (!all_records) {
         // the ordinary batch leaves this pass (next to) nothing: one parallel look at the workgroup's segments first
@@ -385,7 +385,7 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
 {
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if ((mode & 3) != 3 || ((mode & MODE_ALPHA) != 0) != NM) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = mode;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = (host_mode >> 31) ? *mode_word : mode;
 #ifdef CK_MIXED_TIMELINE
     const uint64_t tl_start = wall_clock64();
 #endif
@@ -952,6 +952,7 @@ struct circkit_ctx {
     // uniq table
     UniqSlot* d_table = nullptr;         // [uniq_mask + 2]
     uint64_t uniq_mask = 0, uniq_count = 0;   // slots - 1; upper bound of the keys folded in so far
+    uint32_t mode_seen = 0;                   // launch_canon: the mode word as the previous device batch's launch read it (MODE_GUESS)
     bool uniq_local = false;                  // the table holds circkit_uniq_resolve_device's split local values
     bool uniq_lost = false;                   // a rehash failed half-way: the stream's earlier batches are gone -- every uniq call fails until circkit_uniq_reset
 };
@@ -1019,6 +1020,26 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
+    // MODE_GUESS.  Every mode computes the same results -- the mode only says which builds are the fast ones for the batch's
+    // lengths and alphabet.  A device batch whose mode the host does not know used to launch every build (the ones the
+    // device-side decision does not name return at once): eleven idle kernels per batch, ~5 us each, 3-4 % of a 1.8 ms
+    // batch.  Now the mode the last batches REPORTED (the pinned word the device writes, read here without waiting) is taken as
+    // this batch's mode, exactly as if the host had seen the offsets: only that mode's kernels are launched.  The count
+    // kernel still runs and the kernels report ITS answer (bit 31 of the mode argument), so the guess follows the data: a
+    // batch of another kind runs correctly on the wrong builds (as slow as round 2's general path at worst), the launch after
+    // the one that sees the new report decides on the device again, the one after that guesses the new mode.
+    // CIRCKIT_NO_MODE_GUESS=1: every batch decides on the device, as before.
+    const bool device_decides = host_mode == 0;
+    uint32_t guess_flag = 0;
+    if (device_decides) {
+        static const bool no_guess = getenv("CIRCKIT_NO_MODE_GUESS") != nullptr;
+        const uint32_t seen = *c->h_mode & 7u;
+        if (!no_guess && (seen & 3u) && seen == c->mode_seen) { host_mode = seen; guess_flag = 0x80000000u; }
+        c->mode_seen = seen;
+        static const bool dbg = getenv("CIRCKIT_DEBUG_MODE_GUESS") != nullptr;
+        if (dbg) fprintf(stderr, "[mode guess] n=%llu report=%u -> %s\n", (unsigned long long)n, seen, guess_flag ? "guessed" : "decided on the device");
+    }
+    const uint32_t kmode = host_mode | guess_flag;          // what the kernels get
     // launch geometry: G virtual workgroups for the streaming kernel, the rescue pass and tier A (segment b of a list
     // belongs to workgroup b); stage C and the team stage take several segments per workgroup each
     const bool aux = d_idx || d_strand || (flags & ck::CK_FLAG_FWD_ONLY);
@@ -1072,7 +1093,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     // [3] records nothing could take, [4] uniq table overflow,
     // [5] the batch's mode (device-side decision), [8..10] the count kernel's counters and ticket (it leaves them zero).
     // A device-side decision zeroes [0] and [3] in its count kernel; the host-side one with a memset.
-    if (host_mode) CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    if (!device_decides) CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
@@ -1088,7 +1109,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         // general one for callers that also want the rotation index / strand or the forward-only variant (lmsr);
         // each for ROWS = 1 and ROWS = 2.  The host's answer launches exactly one of the two; a device-side decision
         // launches both, full-size where the previous batch's mode says it will run.
-        if (!host_mode) {
+        if (device_decides) {
             const uint64_t ns = count_samples(n);
             const unsigned cgrid = (unsigned)((ns + 1023) / 1024 < 128 ? (ns + 1023) / 1024 : 128);
             hipLaunchKernelGGL(stream_count_kernel, dim3(cgrid), dim3(1024), 0, c->stream, d_bytes, d_offsets, n, c->d_counters + 8, c->d_counters + 5, c->d_counters);
@@ -1109,8 +1130,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                 const dim3 grid(full ? G : small);
 #define CK_LAUNCH_STREAM(CFG, H, A, BLK, AL)                                                                                         \
                 do {                                                                                                                \
-                    if (full) hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, false, AL>), grid, BLK, 0, c->stream, a, counts, host_mode, G); \
-                    else hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, true, AL>), grid, BLK, 0, c->stream, a, counts, host_mode, G);       \
+                    if (full) hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, false, AL>), grid, BLK, 0, c->stream, a, counts, kmode, G); \
+                    else hipLaunchKernelGGL((canon_stream_kernel<CFG, H, A, true, AL>), grid, BLK, 0, c->stream, a, counts, kmode, G);       \
                 } while (0)
                 if (rows == 1) {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux, false);
@@ -1141,13 +1162,13 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         // both alphabets' builds unless the host has decided; the one the mode does not name returns at once
         const bool mixed_has_it = host_mode && !aux && (host_mode & 3) == 3;
         const bool lean = (!host_mode || !(host_mode & MODE_ALPHA)) && !mixed_has_it, alpha = (!host_mode || (host_mode & MODE_ALPHA)) && !mixed_has_it;
-        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+        if (aux) hipLaunchKernelGGL((canon_rescue_kernel<true, true, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
         else if (d_hash) {
-            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<true, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
-            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<true, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<true, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
+            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<true, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
         } else {
-            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<false, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
-            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+            if (lean) hipLaunchKernelGGL((canon_rescue_kernel<false, false, false>), dim3(grid), dim3(256), 0, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
+            if (alpha) hipLaunchKernelGGL((canon_rescue_kernel<false, false, true>), dim3(grid), dim3(256), 0, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
         }
     }
     if (!aux && (!host_mode || (host_mode & 3) == 3)) {
@@ -1175,11 +1196,11 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
             const size_t shmem = (4 * a.slice_dw + 4 + ck::FAST_LUT_DW + (d_hash ? ck::LEAN_HASH_TABLE_DW : 0)) * 4;
             if (d_hash) {
-                if (nm) hipLaunchKernelGGL(canon_mixed_nh_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
-                else hipLaunchKernelGGL(canon_mixed_h_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+                if (nm) hipLaunchKernelGGL(canon_mixed_nh_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
+                else hipLaunchKernelGGL(canon_mixed_h_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
             } else {
-                if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
-                else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, host_mode, mode_out, c->d_counters + 1);
+                if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
+                else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
             }
         }
     }

@@ -179,3 +179,47 @@ def test_host_batch_page_locked_output(O, shift):
         ctx.close()
     finally:
         del os.environ["CIRCKIT_HOST_BATCH_PARTS"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("want_hash", [False, True])
+def test_mode_guess_follows_the_data(O, want_hash):
+    """launch_canon takes the mode the last device batches reported as the next batch's mode (only that mode's kernels are
+    launched) once two launches in a row have read the same report.  Runs of batches of one kind with a change of kind
+    behind each run -- short records, mixed lengths, short records with N, 1.5 kb records -- so that every change meets a
+    WRONG guess first: the bytes (and hashes) are the oracle's all the same, and every batch reports its OWN mode."""
+    import torch
+    import circkit_amd
+    from tests import seqsets
+    dev = torch.device("cuda", 0)
+    ctx = circkit_amd.Context(0)
+    n = 3000
+    kinds = [(seqsets.random_mixed(301, n, 300, 1008), 1),
+             (seqsets.random_mixed(302, n // 4, 200, 9000) + seqsets.random_mixed(303, n // 4, 2100, 20000), 3),
+             (seqsets.random_mixed(304, n, 200, 1008, b"ACGTACGTACGTACGTACGTN"), 1),
+             (seqsets.random_mixed(305, n, 1400, 1900), 2),
+             (seqsets.random_mixed(306, n // 4, 2500, 12000, b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTN"), 3)]
+    packed = []
+    for seqs, mode in kinds:
+        data, offs = seqsets.pack(seqs)
+        exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+        packed.append((torch.from_numpy(np.concatenate([data, np.zeros(64, dtype=np.uint8)])).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev),
+                       len(seqs), len(data), exp, exp_h, mode))
+    order = [0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 0, 4, 4, 4, 4, 1, 0]
+    for wait in (True, False):          # with a look at the device after every batch, and enqueued back to back
+        outs = []
+        for k in order:
+            d_bytes, d_off, cnt, nb, exp, exp_h, mode = packed[k]
+            d_out = torch.zeros(nb + 64, dtype=torch.uint8, device=dev)
+            d_hash = torch.zeros(cnt, dtype=torch.int64, device=dev) if want_hash else None
+            ctx.canonicalize_batch_device(d_bytes, d_off, cnt, out_bytes=d_out, out_xxh3=d_hash)
+            if wait:
+                assert ctx.last_batch_mode() == mode, (k, mode)
+            outs.append((k, d_out, d_hash))
+        assert ctx.batch_status() == 0
+        for k, d_out, d_hash in outs:
+            _, _, cnt, nb, exp, exp_h, _ = packed[k]
+            assert np.array_equal(d_out[:nb].cpu().numpy(), exp), k
+            if want_hash:
+                assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h), k
+    ctx.close()
