@@ -105,7 +105,8 @@ int circkit_ctx_set_long_record_scratch(circkit_ctx* ctx, uint64_t bytes);
 /* Which build of the streaming kernel the most recent device batch selected, from that batch's own lengths: 1 = one
  * packed word per lane (records up to 1008 b), 2 = two words (a quarter or more of the records in 1009..2032 b),
  * 3 = neither (an eighth or more of the records longer; the per-record passes take everything).  Diagnostic: every
- * mode computes the same results.  Synchronizes. */
+ * mode computes the same results (and the library launches a batch's kernels for the mode the batches before it reported,
+ * so a change of kind costs one or two slower batches, never a wrong answer).  Synchronizes. */
 int circkit_ctx_last_batch_mode(circkit_ctx* ctx, uint32_t* mode);
 
 /* ---- batch, host buffers ---------------------------------------------------------------------- */
