@@ -227,3 +227,34 @@ def test_record_longer_than_a_pipeline_chunk(tmp_path):
     r = subprocess.run([BIN, "uniq", "-c"], input=data, capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert r.stdout == want                                  # all records distinct: uniq -c prints the same file
+
+
+@pytest.mark.parametrize("slots,chunk_mb", [("2", "1"), ("3", "2"), ("32", "1"), ("6", "64")])
+def test_chunk_ring_geometry(tmp_path, slots, chunk_mb):
+    """CIRCKIT_CLI_SLOTS x CIRCKIT_CLI_CHUNK_MB (the ring of chunks in flight: reader -> parsers -> device -> emit -> the
+    writer thread): a 9 MB input with records that straddle chunk ends -- among them one longer than a chunk -- gives the
+    same bytes for every geometry, for canonicalize into a file, uniq into a pipe and uniq --table."""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(11)
+    recs = []
+    for i in range(9000):
+        L = 2_500_000 if i == 4000 else int(rng.integers(1, 2000))
+        s = bytes(rng.choice(list(b"ACGT"), size=L).astype(np.uint8))
+        if i % 7 == 0 and i:
+            s = recs[int(rng.integers(0, len(recs)))][1]
+        recs.append((b"r%d" % i, s))
+    data = b"".join(b">" + h + b"\n" + s + b"\n" for h, s in recs)
+    src = tmp_path / "in.fasta"
+    src.write_bytes(data)
+    env = dict(os.environ, CIRCKIT_CLI_SLOTS=slots, CIRCKIT_CLI_CHUNK_MB=chunk_mb)
+    out = tmp_path / "out.fasta"
+    r = subprocess.run([BIN, "canonicalize", str(src), "-o", str(out)], capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == O.cli_canonicalize(data)
+    want_u, want_t = O.cli_uniq(data, True, delimiter=b"\t")
+    table = tmp_path / "dups.tsv"
+    r = subprocess.run([BIN, "uniq", "-c", str(src), "--table", str(table)], capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == want_u
+    assert table.read_bytes() == want_t
