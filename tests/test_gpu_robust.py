@@ -223,3 +223,22 @@ def test_mode_guess_follows_the_data(O, want_hash):
             if want_hash:
                 assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h), k
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_host_batch_staging_grows_and_shrinks_with_the_batch(O):
+    """The ctx's page-locked staging of offsets / hashes / indices / strands (host_batch) is sized by the largest batch seen:
+    a small batch, a 40x larger one, a small one again through ONE ctx -- every per-record output lands in its place."""
+    import circkit_amd
+    from tests import seqsets
+    ctx = circkit_amd.Context(0)
+    for seed, count in ((401, 500), (402, 20000), (403, 300), (404, 21000), (405, 1)):
+        seqs = seqsets.random_mixed(seed, count, 30, 700)
+        data, offs = seqsets.pack(seqs)
+        got = ctx.canonicalize_batch(data, offs, want_bytes=True, want_index=True, want_strand=True, want_xxh3=True)
+        exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+        assert np.array_equal(got["bytes"], exp) and np.array_equal(got["xxh3"], exp_h)
+        for i in range(0, count, max(1, count // 50)):
+            _, st, idx = seqsets.expected(O, seqs[i])
+            assert int(got["strand"][i]) == st and int(got["index"][i]) == idx, (count, i)
+    ctx.close()
