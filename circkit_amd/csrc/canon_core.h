@@ -64,12 +64,15 @@ struct CanonArgs {
 // kernel ends when its LAST workgroup does: with equal segments the chip drains for one segment's duration (config 4: 32 768
 // segments of ~80 us, 65 us = 3.6 % of the kernel with fewer and fewer CUs at work).  The last segments are therefore smaller,
 // generation by generation, so that whatever is still running when the list runs out is short.
+#ifndef CK_TAPER_GENS
+#define CK_TAPER_GENS 3
+#endif
 CK_DEV void seg_records(const CanonArgs& a, uint32_t s, uint64_t& first, uint32_t& count)
 {
     uint64_t f = (uint64_t)s * a.all_seg_cap;
     uint32_t cap = a.all_seg_cap;
     if (a.taper_log2 != 0 && s >= a.taper_seg0) {
-        const uint32_t k = (s - a.taper_seg0) >> a.taper_log2, g = k < 2 ? k : 2;
+        const uint32_t k = (s - a.taper_seg0) >> a.taper_log2, g = k < CK_TAPER_GENS - 1 ? k : CK_TAPER_GENS - 1;
         f = (uint64_t)a.taper_seg0 * a.all_seg_cap;
         for (uint32_t j = 0; j < g; ++j) f += (uint64_t)(a.all_seg_cap >> (j + 1)) << a.taper_log2;
         cap = a.all_seg_cap >> (g + 1);

@@ -1057,11 +1057,15 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     // a half, a quarter, an eighth of the records of the ones before
     uint32_t taper_seg0 = 0, taper_log2 = 0;
 #ifndef CK_NO_TAPER
-    if (G >= 4096 && all_cap >= 16) {
-        while ((2u << taper_log2) <= G / 16) ++taper_log2;
+#ifndef CK_TAPER_DIV
+#define CK_TAPER_DIV 16
+#endif
+    if (G >= 4096 && all_cap >= (2u << CK_TAPER_GENS)) {
+        while ((2u << taper_log2) <= G / CK_TAPER_DIV) ++taper_log2;
         const uint64_t gen = 1ull << taper_log2;
-        taper_seg0 = G - (uint32_t)(3 * gen);
-        while ((uint64_t)taper_seg0 * all_cap + gen * ((all_cap >> 1) + (all_cap >> 2) + (all_cap >> 3)) < n) ++all_cap;
+        taper_seg0 = G - (uint32_t)(CK_TAPER_GENS * gen);
+        auto tapered = [&](uint32_t A) { uint64_t t = 0; for (int j = 1; j <= CK_TAPER_GENS; ++j) t += A >> j; return t; };
+        while ((uint64_t)taper_seg0 * all_cap + gen * tapered(all_cap) < n) ++all_cap;
         if (cap < all_cap) cap = all_cap;
     }
 #endif
