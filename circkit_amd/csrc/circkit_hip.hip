@@ -230,7 +230,8 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 // the two-word path makes the one-word path ~12 % longer, hence two builds.  Who decides: the host when it has the
 // offsets (host-buffer API); otherwise the device, for every batch anew: stream_count_kernel counts the batch's
 // lengths and every kernel derives the mode from the counters (batch_mode).  The call stays asynchronous: BOTH builds
-// are launched, the one the previous batch used with a full grid, the other with a small one.
+// are launched, the one the previous batch used with a full grid, the other with a small one -- until the batches before
+// have reported the same mode twice: then only that mode's build is launched (launch_canon, MODE_GUESS).
 using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
 using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
 // The build with every output (index / strand / forward-only) needs ~100 SGPRs: at 16 waves per workgroup only one
