@@ -197,6 +197,9 @@ def main():
     torch.cuda.synchronize()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in lanes]
+    import gc
+    gc.collect()
+    gc.disable()            # (a collection inside the 40-100 ms of the timed region once cost a run 19 ms of wall time)
     t0 = time.perf_counter()
     ev0.record(stream)
     for ln in lanes[1:]:
@@ -210,6 +213,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     kernel_ms = max(ev0.elapsed_time(e) for e in ev1) / args.steps      # HIP events on the launch streams
     for ln in lanes:
         unprocessed = ln["ctx"].batch_status()
