@@ -1421,8 +1421,10 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     // With a plain copy-in and a plain copy-out stream -- round 3's first arrangement -- the two directions of a call
     // overlapped or took turns (1 GB: 24.8 or 38-40 ms) depending on how many streams the process had made before: one extra
     // stream ahead of the ctx was slow in 2 runs of 2 (tools/probe_stream_luck.py), and so were bench.py's `uniq` processes.
-    // In this arrangement 130 fresh processes in the same probes were fast but one (40 ms, not reproduced: 72 of 72 in the
-    // same configuration afterwards, tools/probe_duplex_rate.sh).  Moving the bytes out by a copy kernel that stores across
+    // In this arrangement 130 fresh processes in the same probes were fast but one -- which had run straight behind a process
+    // that had just released tens of GB of device memory: for some seconds after such an exit the copy engines are busy with
+    // the driver's handling of that memory and the directions of every process's copies take turns
+    // (tools/probe_after_big_process.sh); nothing a library can do about, bench.py's end-to-end leg waits it out.  Moving the bytes out by a copy kernel that stores across
     // the link instead of the DMA engine: 28 ms, and it took turns as well when it did.
     // CIRCKIT_HOST_BATCH_PLAIN_STREAMS=1: the first arrangement, for comparison.
     static const bool plain_streams = getenv("CIRCKIT_HOST_BATCH_PLAIN_STREAMS") != nullptr;
