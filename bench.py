@@ -416,7 +416,7 @@ def end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out):
         same = bool(torch.equal(got, d_out[first:first + nb].cpu()))
     lib.circkit_host_free(pin_in)
     lib.circkit_host_free(pin_out)
-    return {"value": S / dt, "unit": "sequences/s", "kind": "PCIe-inclusive, host-buffer API (circkit_canonicalize_batch), pinned buffers, one call after the other (inside a call: up to 8 parts, "
+    return {"value": S / dt, "unit": "sequences/s", "kind": "PCIe-inclusive, host-buffer API (circkit_canonicalize_batch), pinned buffers, one call after the other (inside a call: up to 16 parts, "
                                            "copy-in / kernels / copy-out of neighbouring parts overlap)",
             "sample": "first %d records (%d bases) of the batch" % (S, nb), "ms_per_call": dt * 1e3,
             "attempts_ms": [round(x, 3) for x in attempts],

@@ -923,7 +923,7 @@ struct circkit_ctx {
     hipEvent_t ev_order = nullptr;       // circkit_ctx_set_stream: the new stream waits for what the ctx queued on the old one
     // host-buffer batches in parts (host_batch): copy-in and copy-out streams of the ctx's own and one event pair per part, so
     // that part k + 1 arrives and part k - 1 leaves while part k computes (PCIe is full duplex)
-    static constexpr int MAX_PARTS = 8;
+    static constexpr int MAX_PARTS = 32;
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[MAX_PARTS] = {}, ev_done[MAX_PARTS] = {}, ev_head = nullptr;
     bool timed = false;
@@ -1013,7 +1013,7 @@ constexpr uint64_t GSLICE1_DW = 1ull << 20;     // stage 1 of the global-scratch
 // (records beyond the on-chip tiers included: the last two stages take them in a global-memory scratch).
 // host_mode: 1 / 2 / 3 when the host has seen the offsets (stream_mode), 0 = the device decides.
 int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_out,
-                 uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags, uint32_t host_mode = 0)
+                 uint32_t* d_idx, uint8_t* d_strand, uint64_t* d_hash, uint32_t flags, uint32_t host_mode = 0, bool keep_status = false)
 {
 #ifdef CK_FORCE_HOST_MODE
     if (!host_mode) host_mode = CK_FORCE_HOST_MODE;      // experiment: no count kernel, no second build
@@ -1098,7 +1098,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     // [3] records nothing could take, [4] uniq table overflow,
     // [5] the batch's mode (device-side decision), [8..10] the count kernel's counters and ticket (it leaves them zero).
     // A device-side decision zeroes [0] and [3] in its count kernel; the host-side one with a memset.
-    if (!device_decides) CK_HIP(c, hipMemsetAsync(c->d_counters, 0, 4 * sizeof(uint32_t), c->stream));
+    // (keep_status: a later part of a host batch -- counters[3], the records nothing could take, adds up over the parts)
+    if (!device_decides) CK_HIP(c, hipMemsetAsync(c->d_counters, 0, (keep_status ? 3 : 4) * sizeof(uint32_t), c->stream));
     CK_HIP(c, hipEventRecord(c->ev0, c->stream));
     ck::CanonArgs a{};
     a.bytes = d_bytes; a.offsets = d_offsets; a.n_records = n;
@@ -1406,13 +1407,17 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     }
     // ...sizes the global scratch for the longest record, whatever mode it turns out to need
     if (worst_case_dw(max_len) > TIER_D_DW && (rc = ensure_gscratch(c, worst_case_dw(max_len) * 4))) return rc;
-    // The batch goes through the device in PARTS of >= 16 MB (up to eight): part k + 1 is copied in while part k - 1 is copied
+    // The batch goes through the device in PARTS of >= 16 MB (up to sixteen): part k + 1 is copied in while part k - 1 is copied
     // out on a stream of the ctx's own; with page-locked buffers (circkit_host_alloc) the two directions of the link work at
     // the same time.  One part = the round-2 behaviour: in, compute, out, one after the other
     // (1 GB of 1 kb records: 37.9 ms per call, 53 GB/s for both directions together).
     dbg_lap("offset scan");
+    // (measured, tools/probe_host_batch.py: 64 MB in four parts 1.93 ms; 256 MB in eight 6.48 ms, in sixteen 6.84; 1 GB in eight
+    // 25.2 ms, in sixteen 24.3, in thirty-two 24.4-24.8: up to eight parts of 16 MB and more, beyond 512 MB sixteen of 64 MB)
     int parts = (int)(total / (16ull << 20));
-    parts = parts < 1 ? 1 : (parts > circkit_ctx::MAX_PARTS ? circkit_ctx::MAX_PARTS : parts);
+    parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+    if (total > (512ull << 20)) { parts = (int)(total / (64ull << 20)); parts = parts > 16 ? 16 : parts; }
+    parts = parts > circkit_ctx::MAX_PARTS ? circkit_ctx::MAX_PARTS : parts;
     if ((uint64_t)parts > n) parts = (int)n;
     if (getenv("CIRCKIT_HOST_BATCH_PARTS")) { const int p = atoi(getenv("CIRCKIT_HOST_BATCH_PARTS")); if (p >= 1 && p <= circkit_ctx::MAX_PARTS && (uint64_t)p <= n) parts = p; }
     // The copy-in rides the ctx stream itself, part k + 1 queued behind part k's kernels (a few hundred microseconds next to the
@@ -1499,29 +1504,25 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     }
     const uint32_t host_mode = stream_mode(two_word, longer, n) | alpha_mode(bad, nc);
     dbg_lap("content sample");
-    volatile uint32_t* unprocessed = c->h_mode + 4;                       // (pinned: one word per part)
+    volatile uint32_t* unprocessed = c->h_mode + 4;                       // (pinned)
     for (int k = 0; k < parts; ++k) {
         const uint64_t r0 = cut[k], nk = cut[k + 1] - r0, b0 = offsets[r0], b1 = offsets[cut[k + 1]];
         if (!inline_h2d) CK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in[k], 0));
         rc = launch_canon(c, c->d_in, c->d_off + r0, nk, need_bytes ? c->d_out : nullptr, idx ? c->d_idx + r0 : nullptr,
-                          strand ? c->d_strand + r0 : nullptr, hash ? c->d_hash + r0 : nullptr, flags, host_mode);
+                          strand ? c->d_strand + r0 : nullptr, hash ? c->d_hash + r0 : nullptr, flags, host_mode, k > 0);
         if (rc) { if (c->s_in) (void)hipStreamSynchronize(c->s_in); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); return rc; }
         CK_HIP(c, hipEventRecord(c->ev_done[k], c->stream));
         CK_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_done[k], 0));
         if (inline_h2d && k + 1 < parts && (rc = copy_in(k + 1))) return rc;
-        // the part's count of records nothing could take first: the next part's launch zeroes the counter again and waits for
-        // this copy of it (and for nothing else of the copy-out)
-        unprocessed[k] = 0;
-        CK_HIP(c, hipMemcpyAsync((void*)(unprocessed + k), c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->s_out));
-        if (k + 1 < parts) {
-            CK_HIP(c, hipEventRecord(c->ev_head, c->s_out));
-            CK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_head, 0));
-        }
         if (out && b1 > b0) CK_HIP(c, hipMemcpyAsync(out + b0, c->d_out + b0, b1 - b0, hipMemcpyDeviceToHost, c->s_out));
         if (idx) CK_HIP(c, hipMemcpyAsync(st_idx + r0, c->d_idx + r0, nk * 4, hipMemcpyDeviceToHost, c->s_out));
         if (strand) CK_HIP(c, hipMemcpyAsync(st_strand + r0, c->d_strand + r0, nk, hipMemcpyDeviceToHost, c->s_out));
         if (hash) CK_HIP(c, hipMemcpyAsync(st_hash + r0, c->d_hash + r0, nk * 8, hipMemcpyDeviceToHost, c->s_out));
     }
+    // the count of records nothing could take, added up over the parts (only part 0's launch zeroes it): read once, behind the
+    // last part -- a copy of it per part made every part's kernels wait for the copy-out two parts back
+    unprocessed[0] = 0;
+    CK_HIP(c, hipMemcpyAsync((void*)unprocessed, c->d_counters + 3, 4, hipMemcpyDeviceToHost, c->s_out));
     dbg_lap("enqueue parts");
     CK_HIP(c, hipStreamSynchronize(c->s_out));
     dbg_lap("sync copy-out");
@@ -1530,8 +1531,7 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     if (idx) memcpy(idx, st_idx, n * 4);
     if (strand) memcpy(strand, st_strand, n);
     if (hash) memcpy(hash, st_hash, n * 8);
-    uint32_t lost = 0;
-    for (int k = 0; k < parts; ++k) lost += unprocessed[k];
+    const uint32_t lost = unprocessed[0];
     if (lost) return fail(c, CIRCKIT_ERR_TOO_LONG, "%u record(s) could not be processed", lost);
     return CIRCKIT_OK;
 }
@@ -1561,7 +1561,7 @@ int circkit_ctx_create(int device, circkit_ctx** out)
     CK_HIP(c, hipEventCreate(&c->ev0));
     CK_HIP(c, hipEventCreate(&c->ev1));
     CK_HIP(c, hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
-    CK_HIP(c, hipHostMalloc((void**)&c->h_mode, 64, hipHostMallocMapped));
+    CK_HIP(c, hipHostMalloc((void**)&c->h_mode, 256, hipHostMallocMapped));      // [0] mode, [1] tiers-busy flag, [4 .. 4 + MAX_PARTS) host_batch's per-part status
     c->h_mode[0] = 0; c->h_mode[1] = 0;
     CK_HIP(c, hipHostGetDevicePointer((void**)&c->d_mode, (void*)c->h_mode, 0));
     CK_HIP(c, hipMalloc(&c->d_comp, 256));

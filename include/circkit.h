@@ -112,9 +112,9 @@ int circkit_ctx_last_batch_mode(circkit_ctx* ctx, uint32_t* mode);
 /* ---- batch, host buffers ---------------------------------------------------------------------- */
 /* Same contract with HOST pointers: copies the batch into ctx-owned device buffers (grow-only), runs
  * circkit_canonicalize_batch_device, copies the requested outputs back and returns when they are complete.
- * Batches of 32 MB and more go through the device in up to eight parts: part k + 1 is copied in (on the ctx stream, behind
+ * Batches of 32 MB and more go through the device in up to sixteen parts: part k + 1 is copied in (on the ctx stream, behind
  * part k's kernels) while part k - 1 is copied out (on a stream of the ctx's own), so with page-locked buffers both
- * directions of the link are busy at once (1 GB of 1 kb records: 25 ms per call instead of 38; 64 MB: 2.0 ms; 16 MB: 0.8).
+ * directions of the link are busy at once (1 GB of 1 kb records: 23-24 ms per call instead of 38; 64 MB: 2.0 ms; 16 MB: 0.8).
  * The offsets and the per-record outputs cross through page-locked staging of the ctx, whatever memory the caller's are in.
  * Buffers from circkit_host_alloc (page-locked) are copied by DMA; pageable memory goes through the runtime's
  * staging.  Streaming hosts overlap this call with their own parsing / writing (see circkit_cli.cpp).

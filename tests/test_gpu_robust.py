@@ -114,7 +114,7 @@ def test_hash_only_device_batches_enqueue_without_a_look_at_the_device(O):
     ctx.close()
 
 
-@pytest.mark.parametrize("parts", ["1", "2", "3", "8"])
+@pytest.mark.parametrize("parts", ["1", "2", "3", "8", "16", "32"])
 def test_host_batch_in_parts(O, parts):
     """circkit_canonicalize_batch moves a host batch through the device in parts (copy-in / kernels / copy-out of
     neighbouring parts overlap on the ctx's own copy streams; 16 MB and more per part by default, forced here on a small
