@@ -47,6 +47,7 @@ def pmc_traffic(workload):
 def self_launch(n_ranks):
     """One process per GPU, started from here: the launcher is a CHILD (never exec: this process may already hold state the
     box forbids replacing), stdout / stderr are inherited so rank 0's JSON line is this command's output."""
+    import signal
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -55,7 +56,25 @@ def self_launch(n_ranks):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # the launcher and its ranks get a session of their own: a SIGTERM / SIGINT that reaches only this process (a driver's
+    # timeout) is passed on to the whole group, and nothing is left behind holding GPU memory when this process goes
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def forward(signum, _frame):
+        try:
+            os.killpg(child.pid, signum)
+        except ProcessLookupError:
+            pass
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, forward)
+    try:
+        return child.wait()
+    finally:
+        if child.poll() is None:
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
 
 
 def main():
@@ -72,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-buffer leg (end_to_end)")
     ap.add_argument("--no-copy", action="store_true", help="skip the same-box plain-copy yardstick (roofline.copy_ceiling_gbps)")
+    ap.add_argument("--no-others", action="store_true",
+                    help="default run (canonicalize, 1 GPU) only: skip the `other_workloads` block -- BASELINE configs[2] and [3] and their "
+                         "variants, 5 steps each in the same process AFTER the headline's timed region (never inside it; `value` is untouched)")
     ap.add_argument("--exchange", default="partition", choices=["partition", "allgather"], help="uniq at --gpus > 1")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (each with its own ctx and output buffers) the steps are dealt to round-robin, so that the "
@@ -151,7 +173,15 @@ def main():
         d_bytes, d_off = W.fixed_length(ctx, dev, N, L, 42, rank * N)
     if args.n_frac > 0:
         W.sprinkle_n(d_bytes, total, args.n_frac, 46 + rank, dev)
-    if args.workload == "uniq":
+    if args.workload == "uniq" and world > 1:
+        # config 3 over the whole job: a duplicate's original lives on ANY rank (7 of 8 on another one at world 8), so the
+        # kept count and the first-seen indices are only right if the exchange resolves first-seen ACROSS ranks
+        def fill(seed, first_base, n_bases):
+            buf = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+            ctx.synth_fill_device(seed, first_base, n_bases, buf)
+            return buf
+        W.plant_job_duplicates(fill, d_bytes, N, L, dev, rank, world)
+    elif args.workload == "uniq":
         W.plant_duplicates(d_bytes, N, L, dev, 43 + rank, 44 + rank)          # config 3
     torch.cuda.synchronize()
 
@@ -227,8 +257,26 @@ def main():
         if use_dist:
             dist.all_reduce(u)
         unique_global = int(u.item())
-        if L >= 64 and unique_global != world * (N - N // 2):        # 1 kb random records collide with negligible probability
-            raise SystemExit("uniq kept %d records, expected %d" % (unique_global, world * (N - N // 2)))
+        if L >= 64 and unique_global != world * (N // 2):            # 1 kb random records collide with negligible probability
+            raise SystemExit("uniq kept %d records, expected %d" % (unique_global, world * (N // 2)))
+        if world > 1:
+            # every record of every shard against the job-wide expectation (first-seen = smallest GLOBAL index with the same
+            # base record, from the planting decisions every rank can recompute), then an oracle slice per rank that ties the
+            # planting decisions to the bytes.  A rank that fails makes every rank exit non-zero.
+            wrong, cross, distinct, keys = W.job_check(state["fs"], state["keep"], N, L, world, rank, dev)
+            slice_err = job_oracle_slice(np, torch, args, N, L, rank, d_bytes, state, keys) if not args.no_cpu else None
+            bad = torch.tensor([wrong + (1 if slice_err else 0), cross], dtype=torch.int64, device=dev)
+            dist.all_reduce(bad)
+            uniq_job_check = {"records_checked_per_rank": N, "first_seen_mismatches_job": int(bad[0]), "records_owned_by_another_rank_job": int(bad[1]),
+                              "oracle_slice": "first %d records of every rank: canonical bytes + XXH3 vs the oracle, and each record's canonical form == "
+                                              "the oracle's canonical form of the base record its key names (regenerated on the host)" % min(N, 20_000)
+                                              if not args.no_cpu else None}
+            if slice_err:
+                print("rank %d: %s" % (rank, slice_err), file=sys.stderr)
+            if int(bad[0]):
+                raise SystemExit("uniq: %d first-seen / keep mismatches against the job-wide expectation (rank %d: %d)" % (int(bad[0]), rank, wrong))
+            if distinct != world * (N // 2) or int(bad[1]) == 0:
+                raise SystemExit("uniq workload is not the cross-rank one it should be (distinct %d, cross-rank owners %d)" % (distinct, int(bad[1])))
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -315,6 +363,8 @@ def main():
         }
         if unique_global is not None:
             result["unique_records"] = unique_global
+        if args.workload == "uniq" and world > 1:
+            result["uniq_job_check"] = uniq_job_check
         args._state_hash = state["hash"]
         if world == 1 and not args.no_e2e:
             result["end_to_end"] = end_to_end(np, torch, circkit_amd, ctx, args, N, L, d_bytes, d_off, d_out)
@@ -323,11 +373,141 @@ def main():
             if not result["cpu_baseline"]["gpu_output_matches"]:
                 print(json.dumps(result))
                 raise SystemExit("GPU output differs from the CPU oracle on the sample")
+        if world == 1 and args.workload == "canonicalize" and not args.no_others and not args.n_frac and S == 1:
+            t_o = time.perf_counter()
+            result["other_workloads"] = other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_out, N, L, not args.no_cpu)
+            result["other_workloads"]["wall_s"] = time.perf_counter() - t_o
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
     for ln in lanes:
         ln["ctx"].close()
+
+
+def job_oracle_slice(np, torch, args, N, L, rank, d_bytes, state, keys):
+    """Checker leg of a multi-rank `uniq` run (the oracle as the checker, on every rank, never timed): the first records of
+    this rank's shard -- canonical bytes and XXH3 against the oracle, and the planting decisions against the bytes: the
+    canonical form of record p must be the oracle's canonical form of the job's base record keys[p], regenerated on the
+    host from the counter-based generator.  Returns an error text or None."""
+    from oracle import oracle as O
+    S = min(N, 20_000)
+    h_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(L)
+    h_in = d_bytes[:S * L].cpu().numpy()
+    exp, exp_h = O.canonicalize_batch(h_in, h_off, True, True, threads=min(8, len(os.sched_getaffinity(0))))
+    if not args.hash_only and not np.array_equal(exp, state["out"][:S * L].cpu().numpy()):
+        return "canonical bytes differ from the oracle on the slice"
+    if not np.array_equal(exp_h.view(np.int64), state["hash"][:S].cpu().numpy()):
+        return "XXH3 differs from the oracle on the slice"
+    k = keys[:S].cpu().numpy()
+    base = np.concatenate([O.synth_fill(42, int(g) * L, L) for g in k.tolist()])
+    base_canon, _ = O.canonicalize_batch(base, h_off, True, False, threads=min(8, len(os.sched_getaffinity(0))))
+    if not np.array_equal(base_canon, exp):
+        return "a record's canonical form is not that of the base record its key names"
+    return None
+
+
+def other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_out, N, L, check, steps=5):
+    """The other BASELINE configs one GPU holds, on the driver's box: `uniq` (configs[2]) with and without canonical bytes,
+    the mixed-length batch (configs[3]) plain, with 1 % N and with the XXH3 -- warm-up + `steps` timed steps each (HIP events on
+    the launch stream), AFTER everything of the headline.  Per workload: ms per step, algorithmic bytes (2L + 8 per
+    record, + 8 with the hash, L + 16 hash-only), fraction of the 8 TB/s peak, and the oracle (the checker) on a slice."""
+    from circkit_amd import uniq as U
+    from circkit_amd import workloads as W
+    if check:
+        from oracle import oracle as O
+    table = U.DeviceTable(ctx)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    res = {}
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        left = ctx.batch_status()
+        if left:
+            raise SystemExit("other_workloads: %d records were not processed" % left)
+        return e0.elapsed_time(e1) / steps
+
+    def entry(name, wl, ms, n, algo, ok, **more):
+        res[name] = dict({"workload": wl, "ms_per_step": ms, "sequences_per_s": n / (ms * 1e-3), "algorithmic_bytes": algo,
+                          "frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "steps": steps, "oracle_slice_matches": ok}, **more)
+        if ok is False:
+            print(json.dumps({"other_workloads": res}))
+            raise SystemExit("other_workloads: %s differs from the CPU oracle on the slice" % name)
+
+    # ---- configs[2]: the headline's batch with half of it turned into rotated / reverse-complemented copies, shuffled
+    total = N * L
+    W.plant_duplicates(d_bytes, N, L, dev, 43, 44)
+    d_hash = torch.empty(N, dtype=torch.int64, device=dev)
+    st = {}
+
+    def uniq_step(out):
+        ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=out, out_xxh3=d_hash)
+        st["fs"], st["keep"] = U.first_seen(table, d_hash, base_index=0)
+    S = min(N, 20_000)
+    if check:
+        h_off = np.arange(S + 1, dtype=np.uint64) * np.uint64(L)
+        exp, exp_h = O.canonicalize_batch(d_bytes[:S * L].cpu().numpy(), h_off, True, True, threads=threads)
+        exp_fs = O.uniq_first_seen(exp_h).astype(np.int64)
+    for name, out in (("uniq", d_out), ("uniq_hash_only", None)):
+        if out is None:
+            d_hash.zero_()
+        ms = timed(lambda: uniq_step(out))
+        table.check()
+        kept = int(st["keep"].sum())
+        ok = None
+        if check:
+            ok = bool(np.array_equal(d_hash[:S].cpu().numpy(), exp_h.view(np.int64))) and \
+                bool(np.array_equal(st["fs"][:S].cpu().numpy().astype(np.int64), exp_fs)) and \
+                (out is None or bool(np.array_equal(out[:S * L].cpu().numpy(), exp))) and (L < 64 or kept == N - N // 2)
+        entry(name, "uniq %s, %d x %d b, ~50 %% rotational/strand duplicates (BASELINE configs[2])%s" % (
+            "--canonicalize" if out is not None else "without --canonicalize: no canonical bytes written", N, L, "" if (N, L) == (10_000_000, 1000) else " at this run's size"),
+            ms, N, (2 * total + 16 * N) if out is not None else (total + 16 * N), ok, unique_records=kept,
+            check="first %d records: XXH3 + first-seen%s vs the oracle; kept == N/2" % (S, " + canonical bytes" if out is not None else ""))
+    del d_hash
+    # ---- configs[3]: 1M records, lengths log-uniform on [200, 20000]; then with 1 % N; the plain one also with the XXH3
+    M = 1_000_000
+    offs = W.log_uniform_offsets(M, 45, 200, 20000)
+    mtotal = int(offs[-1])
+    m_off = offs.to(dev)
+    m_in = d_bytes[:mtotal + 64] if d_bytes.numel() >= mtotal + 64 else torch.empty(mtotal + 64, dtype=torch.uint8, device=dev)
+    m_out = d_out[:mtotal + 64] if d_out.numel() >= mtotal + 64 else torch.empty(mtotal + 64, dtype=torch.uint8, device=dev)
+    ctx.synth_fill_device(45, 0, mtotal, m_in)
+    m_hash = torch.empty(M, dtype=torch.int64, device=dev)
+    SM = 4000
+    mh_off = offs[:SM + 1].numpy().astype(np.uint64)
+    mnb = int(mh_off[-1])
+
+    def mixed_check(with_hash):
+        if not check:
+            return None
+        e, eh = O.canonicalize_batch(m_in[:mnb].cpu().numpy(), mh_off, True, with_hash, threads=threads)
+        ok = bool(np.array_equal(m_out[:mnb].cpu().numpy(), e))
+        return ok and (not with_hash or bool(np.array_equal(m_hash[:SM].cpu().numpy(), eh.view(np.int64))))
+    wl = "%d records, lengths log-uniform on [200, 20000], %d bases (BASELINE configs[3])" % (M, mtotal)
+    ms = timed(lambda: ctx.canonicalize_batch_device(m_in, m_off, M, out_bytes=m_out))
+    entry("mixed", "canonicalize, " + wl, ms, M, 2 * mtotal + 8 * M, mixed_check(False), check="first %d records: canonical bytes vs the oracle" % SM)
+
+    def mixed_hash_step():
+        ctx.canonicalize_batch_device(m_in, m_off, M, out_bytes=m_out, out_xxh3=m_hash)
+        st["fs"], st["keep"] = U.first_seen(table, m_hash, base_index=0)
+    ms = timed(mixed_hash_step)
+    table.check()
+    entry("mixed_with_hash", "uniq --canonicalize (canonicalize + XXH3 + first-seen), " + wl, ms, M, 2 * mtotal + 16 * M, mixed_check(True),
+          unique_records=int(st["keep"].sum()), check="first %d records: canonical bytes + XXH3 vs the oracle" % SM)
+    W.sprinkle_n(m_in, mtotal, 0.01, 46, dev)
+    ms = timed(lambda: ctx.canonicalize_batch_device(m_in, m_off, M, out_bytes=m_out))
+    entry("mixed_n1pct", "canonicalize, " + wl + ", 1 % of the bases replaced by N", ms, M, 2 * mtotal + 8 * M, mixed_check(False),
+          check="first %d records: canonical bytes vs the oracle" % SM)
+    res["note"] = ("same process and box as the headline, after its timed region and checks; one HIP stream; each entry = 2 warm-up + %d timed "
+                   "steps of the whole kernel chain of that workload (HIP events on the launch stream); frac = algorithmic_bytes / time / 8 TB/s" % steps)
+    return res
 
 
 def copy_ceiling(torch, ctx, stream, d_src, d_dst, total, achieved):

@@ -98,6 +98,8 @@ def load_library():
                 fn = getattr(lib, name)      # AttributeError here = header/library mismatch
             except AttributeError:
                 if os.environ.get("CIRCKIT_LIB"):    # an explicitly chosen variant (e.g. an older round's build in an A/B run) may lack newer symbols
+                    import warnings
+                    warnings.warn("CIRCKIT_LIB=%s lacks %s (a stale variant build?): calls of it will fail" % (LIB_PATH, name))
                     continue
                 raise
             fn.restype, fn.argtypes = res, args

@@ -1056,7 +1056,12 @@ CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block
 {
     if (lane_id() == 0) {
         if (a.defer_list) a.defer_list[(uint64_t)block * a.out_seg_cap + lds_atomic_inc(blk_count)] = rec | (not_acgt ? ENTRY_NOT_ACGT : 0u);
-        else atomic_add_u32(a.status, 1u);
+        else {
+            // nothing can take this record (CIRCKIT_ERR_TOO_LONG through circkit_ctx_batch_status): a hash-only batch must not
+            // find a stale view of an earlier batch in its place (out-of-bounds reads in the xxh3 pass)
+            atomic_add_u32(a.status, 1u);
+            if (a.out_view) a.out_view[rec] = 0;
+        }
     }
 }
 

@@ -31,6 +31,7 @@
 #include <deque>
 #include <new>
 #include <mutex>
+#include <climits>
 #include <string>
 #include <thread>
 #include <vector>
@@ -76,54 +77,113 @@ void usage(FILE* f)
             "  canonicalize and uniq run on the GPU; rotate, cat and decat are byte copies done on the host.\n");
 }
 
+// clap's accepted forms for the arms this binary provides (src/commands.rs:6-14,93-180; clap 3 derive defaults): long options
+// as `--name value` or `--name=value`; short options as `-o value`, `-ovalue`, `-o=value`; short flags and one trailing valued
+// short combined in a cluster (`-ct4`); `--` ends the options; the global `-v/--verbose` and `-q/--quiet` of clap_verbosity_flag
+// (repeatable, `global = true`: before or after the subcommand) -- they set the reference's log level and are no-ops here (this
+// binary logs nothing); `-h/--help`, `-V/--version`.  Errors are clap's: a message on stderr, exit code 2.
+[[noreturn]] void arg_error(const std::string& msg)
+{
+    fprintf(stderr, "error: %s\n\nFor more information try --help\n", msg.c_str());
+    exit(2);
+}
+long long parse_int(const std::string& v, const char* what, long long lo, long long hi)
+{
+    char* end = nullptr;
+    errno = 0;
+    const long long x = strtoll(v.c_str(), &end, 10);
+    if (v.empty() || *end || errno || x < lo || x > hi) arg_error("invalid value '" + v + "' for '" + what + "'");
+    return x;
+}
+bool is_verbosity_arg(const std::string& a)
+{
+    if (a == "--verbose" || a == "--quiet") return true;
+    if (a.size() < 2 || a[0] != '-' || a[1] == '-') return false;
+    for (size_t k = 1; k < a.size(); ++k) if (a[k] != 'v' && a[k] != 'q') return false;
+    return true;
+}
+
 Options parse_args(int argc, char** argv)
 {
     Options o;
-    if (argc < 2) { usage(stderr); exit(2); }
-    o.cmd = argv[1];
+    int i = 1;
+    while (i < argc && is_verbosity_arg(argv[i])) ++i;          // global flags in front of the subcommand
+    if (i >= argc) { usage(stderr); exit(2); }
+    o.cmd = argv[i++];
     if (o.cmd == "-h" || o.cmd == "--help" || o.cmd == "help") { usage(stdout); exit(0); }
+    if (o.cmd == "-V" || o.cmd == "--version") { printf("circkit 0.1.0 (MI355X build)\n"); exit(0); }
     if (o.cmd != "canonicalize" && o.cmd != "uniq" && o.cmd != "rotate" && o.cmd != "cat" && o.cmd != "decat") {
         fprintf(stderr, "error: unrecognized subcommand '%s' (this build provides canonicalize, uniq, rotate, cat, decat)\n", o.cmd.c_str());
         exit(2);
     }
-    const bool gpu_cmd = o.cmd == "canonicalize" || o.cmd == "uniq";
-    for (int i = 2; i < argc; ++i) {
-        const std::string a = argv[i];
-        auto value = [&](const char* name) -> std::string {
-            if (i + 1 >= argc) { fprintf(stderr, "error: %s needs a value\n", name); exit(2); }
-            return argv[++i];
-        };
-        if (a == "-o" || a == "--output") { o.output = value("--output"); o.has_output = true; }
-        else if (a.rfind("--output=", 0) == 0) { o.output = a.substr(9); o.has_output = true; }
-        else if (gpu_cmd && (a == "-t" || a == "--threads")) o.threads = atoi(value("--threads").c_str());
-        else if (gpu_cmd && a.rfind("--threads=", 0) == 0) o.threads = atoi(a.c_str() + 10);
-        else if (gpu_cmd && a == "--device") o.device = atoi(value("--device").c_str());
-        else if (o.cmd == "rotate" && (a == "-b" || a == "--bases" || a.rfind("--bases=", 0) == 0)) {
-            const std::string v = a.rfind("--bases=", 0) == 0 ? a.substr(8) : value("--bases");      // negative values allowed (src/commands.rs:164)
-            char* end = nullptr;
-            o.bases = strtoll(v.c_str(), &end, 10);
-            if (v.empty() || *end) { fprintf(stderr, "error: invalid value '%s' for '--bases <BASES>'\n", v.c_str()); exit(2); }
-            o.has_bases = true;
-        }
-        else if (o.cmd == "rotate" && (a == "-p" || a == "--percent" || a.rfind("--percent=", 0) == 0)) {
-            const std::string v = a.rfind("--percent=", 0) == 0 ? a.substr(10) : value("--percent");
+    const bool gpu_cmd = o.cmd == "canonicalize" || o.cmd == "uniq", uniq = o.cmd == "uniq", rotate = o.cmd == "rotate";
+    // the valued options of this arm, by canonical long name
+    auto set_value = [&](const std::string& name, const std::string& v) {
+        if (name == "output") { o.output = v; o.has_output = true; }
+        else if (name == "threads") o.threads = (int)parse_int(v, "--threads <THREADS>", 0, 2147483647ll);
+        else if (name == "device") o.device = (int)parse_int(v, "--device <N>", 0, 1 << 20);
+        else if (name == "table") { o.table = v; o.has_table = true; }
+        else if (name == "bases") { o.bases = parse_int(v, "--bases <BASES>", LLONG_MIN, LLONG_MAX); o.has_bases = true; }      // negative values allowed (src/commands.rs:164)
+        else {
             char* end = nullptr;
             o.percent = strtod(v.c_str(), &end);
-            if (v.empty() || *end) { fprintf(stderr, "error: invalid value '%s' for '--percent <PERCENT>'\n", v.c_str()); exit(2); }
+            if (v.empty() || *end) arg_error("invalid value '" + v + "' for '--percent <PERCENT>'");
             o.has_percent = true;
         }
-        else if (o.cmd == "uniq" && (a == "-c" || a == "--canonicalize" || a == "--norm" || a == "--canon")) o.canonicalize = true;
-        else if (o.cmd == "uniq" && a == "--table") { o.table = value("--table"); o.has_table = true; }
-        else if (o.cmd == "uniq" && a.rfind("--table=", 0) == 0) { o.table = a.substr(8); o.has_table = true; }
-        else if (a == "-h" || a == "--help") { usage(stdout); exit(0); }
-        else if (!a.empty() && a[0] == '-' && a != "-") { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); exit(2); }
-        else if (!o.has_input) { o.input = a; o.has_input = true; }
-        else { fprintf(stderr, "error: unexpected argument '%s'\n", a.c_str()); exit(2); }
+    };
+    auto long_takes_value = [&](const std::string& n) {
+        return n == "output" || (gpu_cmd && (n == "threads" || n == "device")) || (uniq && n == "table") || (rotate && (n == "bases" || n == "percent"));
+    };
+    auto short_name = [&](char ch) -> const char* {             // valued shorts
+        if (ch == 'o') return "output";
+        if (gpu_cmd && ch == 't') return "threads";
+        if (rotate && ch == 'b') return "bases";
+        if (rotate && ch == 'p') return "percent";
+        return nullptr;
+    };
+    auto next_value = [&](const std::string& shown) -> std::string {
+        if (i + 1 >= argc) arg_error("the argument '" + shown + "' requires a value but none was supplied");
+        return argv[++i];
+    };
+    bool only_positional = false;
+    for (; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (only_positional || a.size() < 2 || a[0] != '-') {         // a positional ("-" included: a path like any other)
+            if (o.has_input) arg_error("unexpected argument '" + a + "' found");
+            o.input = a; o.has_input = true;
+            continue;
+        }
+        if (a == "--") { only_positional = true; continue; }
+        if (a[1] == '-') {
+            const size_t eq = a.find('=');
+            const std::string name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            if (long_takes_value(name)) set_value(name, eq == std::string::npos ? next_value(a) : a.substr(eq + 1));
+            else if (eq != std::string::npos) arg_error("unexpected value '" + a.substr(eq + 1) + "' for '--" + name + "' found; no more were expected");
+            else if (uniq && (name == "canonicalize" || name == "norm" || name == "canon")) o.canonicalize = true;
+            else if (name == "verbose" || name == "quiet") {}
+            else if (name == "help") { usage(stdout); exit(0); }
+            else if (name == "version") { printf("circkit 0.1.0 (MI355X build)\n"); exit(0); }
+            else arg_error("unexpected argument '" + a + "' found");
+            continue;
+        }
+        for (size_t k = 1; k < a.size(); ++k) {                      // a cluster of shorts
+            const char ch = a[k];
+            if (const char* name = short_name(ch)) {
+                std::string v;
+                if (k + 1 < a.size()) { v = a.substr(k + 1); if (v[0] == '=') v = v.substr(1); }
+                else v = next_value(std::string("-") + ch);
+                set_value(name, v);
+                break;
+            }
+            if (uniq && ch == 'c') o.canonicalize = true;
+            else if (ch == 'v' || ch == 'q') {}
+            else if (ch == 'h') { usage(stdout); exit(0); }
+            else if (ch == 'V') { printf("circkit 0.1.0 (MI355X build)\n"); exit(0); }
+            else arg_error(std::string("unexpected argument '-") + ch + "' found");
+        }
     }
-    if (o.has_bases && o.has_percent) {         // src/commands.rs:164,170: the two flags exclude each other
-        fprintf(stderr, "error: the argument '--bases <BASES>' cannot be used with '--percent <PERCENT>'\n");
-        exit(2);
-    }
+    if (o.has_bases && o.has_percent)           // src/commands.rs:164,170: the two flags exclude each other
+        arg_error("the argument '--bases <BASES>' cannot be used with '--percent <PERCENT>'");
     return o;
 }
 

@@ -1361,10 +1361,26 @@ int ensure_staging(circkit_ctx* c, uint64_t bytes, uint64_t recs)
     return CIRCKIT_OK;
 }
 
+int host_batch_enqueue(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* out,
+                       uint32_t* idx, uint8_t* strand, uint64_t* hash, uint32_t flags);
+// Every error exit of the host-buffer path drains the ctx's streams before it returns: copies of earlier parts into the caller's
+// `out` and out of the ctx's page-locked staging may still be in flight when a later part fails, and the caller is free to
+// release its buffers the moment the call is back.
 int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* out,
                uint32_t* idx, uint8_t* strand, uint64_t* hash, uint32_t flags)
 {
     if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    const int rc = host_batch_enqueue(c, bytes, offsets, n, out, idx, strand, hash, flags);
+    if (rc != CIRCKIT_OK) {
+        if (c->s_in) (void)hipStreamSynchronize(c->s_in);
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        if (c->s_out) (void)hipStreamSynchronize(c->s_out);
+    }
+    return rc;
+}
+int host_batch_enqueue(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* out,
+                       uint32_t* idx, uint8_t* strand, uint64_t* hash, uint32_t flags)
+{
     if (n && (!offsets || offsets[0] != 0)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "offsets[0] must be 0");
     if (n == 0) return CIRCKIT_OK;
     const uint64_t total = offsets[n];
@@ -1383,6 +1399,7 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
     };
     uint64_t two_word = 0, longer = 0, max_len = 0;   // the host has the offsets: it picks the streaming kernel's build
     for (uint64_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(c, CIRCKIT_ERR_INVALID_ARG, "offsets decrease at record %llu", (unsigned long long)i);
         const uint64_t len = offsets[i + 1] - offsets[i];
         two_word += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
         longer += len > ck::FAST2_MAX_N;
@@ -1510,7 +1527,7 @@ int host_batch(circkit_ctx* c, const uint8_t* bytes, const uint64_t* offsets, ui
         if (!inline_h2d) CK_HIP(c, hipStreamWaitEvent(c->stream, c->ev_in[k], 0));
         rc = launch_canon(c, c->d_in, c->d_off + r0, nk, need_bytes ? c->d_out : nullptr, idx ? c->d_idx + r0 : nullptr,
                           strand ? c->d_strand + r0 : nullptr, hash ? c->d_hash + r0 : nullptr, flags, host_mode, k > 0);
-        if (rc) { if (c->s_in) (void)hipStreamSynchronize(c->s_in); (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->s_out); return rc; }
+        if (rc) return rc;                                  // (host_batch drains the streams)
         CK_HIP(c, hipEventRecord(c->ev_done[k], c->stream));
         CK_HIP(c, hipStreamWaitEvent(c->s_out, c->ev_done[k], 0));
         if (inline_h2d && k + 1 < parts && (rc = copy_in(k + 1))) return rc;
@@ -1614,8 +1631,13 @@ static int switch_stream(circkit_ctx* c, hipStream_t s)
 {
     if (s == c->stream) return CIRCKIT_OK;
     CK_HIP(c, hipSetDevice(c->device));
-    CK_HIP(c, hipEventRecord(c->ev_order, c->stream));
-    CK_HIP(c, hipStreamWaitEvent(s, c->ev_order, 0));
+    // the stream being left may be gone already (an external stream its owner destroyed): the ordering then falls back to a
+    // host-side wait for the device, and the ctx still moves -- it must not stay bound to a dead stream for good
+    if (hipEventRecord(c->ev_order, c->stream) != hipSuccess || hipStreamWaitEvent(s, c->ev_order, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
     c->stream = s;
     return CIRCKIT_OK;
 }

@@ -233,7 +233,10 @@ CK_DEV uint64_t xxh3_64_wave(const uint8_t* in, uint32_t len) { return xxh3_64_w
 // the canonical record as a view of the input record s[0, n): view = rotation | strand << 31 (CanonArgs::out_view)
 CK_DEV uint64_t xxh3_64_wave_view(const uint8_t* s, uint32_t n, uint32_t view, const uint8_t* comp, const XWaveConst& k)
 {
-    return xxh3_64_wave_r(XView{ s, n, view & 0x7FFFFFFFu, (view >> 31) != 0, comp }, n, k);
+    // a rotation outside the record is not a view (a record no stage could take leaves none: its slot of the ctx's view array
+    // is whatever an earlier batch wrote there): hashed as the record itself, never addressed with
+    const uint32_t rot = view & 0x7FFFFFFFu;
+    return xxh3_64_wave_r(XView{ s, n, rot < n ? rot : 0u, (view >> 31) != 0, comp }, n, k);
 }
 
 }  // namespace ck

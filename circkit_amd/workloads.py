@@ -85,3 +85,84 @@ def revcomp_rotate_csr(d_bytes, d_off, n_records, dev, shift=137, chunk=50_000):
         src = o[:-1][rec] + (ln - 1 - (j + shift) % ln)
         out[b0:b1] = lut[d_bytes[src].long()]
     return out
+
+
+# ---- config 3 over a whole multi-GPU job: duplicates whose original lives on ANOTHER rank -------------------------------
+# The reference keeps the first record of each hash over the WHOLE input (src/uniq.rs:27,47-48).  A sharded job whose
+# duplicates all sit in their original's shard cannot tell a working exchange from one that returns every rank's local
+# answer, so here the second half of every rank's records are copies of base records drawn from ALL ranks' first halves.
+# The base generator is counter-based (include/circkit.h, circkit_synth_fill_device): record g of the job is bases
+# [g*L, (g+1)*L) of the seed stream, so any rank regenerates any other rank's base records locally -- no communication
+# while building the workload, and every rank can also compute the job-wide expectation by itself.
+def job_draws(n_records, length, world, rank, dev, seed_dup=43, seed_shuffle=44):
+    """The planting decisions of `rank` (the same on whoever asks, given the same device type): for each of the n - n//2
+    duplicates its source rank, source base record (< n//2), rotation and strand flip; and the shuffle of the shard."""
+    half = n_records // 2
+    d = n_records - half
+    gen = torch.Generator(device=dev).manual_seed(seed_dup + rank)
+    src_rank = torch.randint(0, world, (d,), generator=gen, device=dev)
+    src_j = torch.randint(0, max(half, 1), (d,), generator=gen, device=dev)
+    k = torch.randint(0, length, (d,), generator=gen, device=dev)
+    flip = torch.rand(d, generator=gen, device=dev) < 0.5
+    perm = torch.randperm(n_records, generator=torch.Generator(device=dev).manual_seed(seed_shuffle + rank), device=dev)
+    return src_rank, src_j, k, flip, perm
+
+
+def job_keys(n_records, length, world, rank, dev, seed_dup=43, seed_shuffle=44):
+    """key[p] of position p of rank's shard = job-wide index of the base record it is a copy of (itself for a base record):
+    two records of the job have the same canonical form iff their keys are equal (random 1 kb records do not collide)."""
+    half = n_records // 2
+    src_rank, src_j, _, _, perm = job_draws(n_records, length, world, rank, dev, seed_dup, seed_shuffle)
+    pre = torch.empty(n_records, dtype=torch.int64, device=dev)
+    pre[:half] = rank * n_records + torch.arange(half, device=dev)
+    pre[half:] = src_rank * n_records + src_j
+    return pre[perm]
+
+
+def plant_job_duplicates(fill, d_bytes, n_records, length, dev, rank, world, seed=42, seed_dup=43, seed_shuffle=44, chunk=500_000):
+    """In place, on a shard already filled with records [rank*n, (rank+1)*n) of the seed stream: records [n/2, n) become
+    rotated / reverse-complemented copies of base records of ANY rank, then the shard is shuffled.
+    fill(seed, first_base, n_bases) -> uint8 tensor on `dev` with those bases of the stream (the ctx's generator on a GPU,
+    the checker's on the CPU tests)."""
+    half = n_records // 2
+    src_rank, src_j, k, flip, perm = job_draws(n_records, length, world, rank, dev, seed_dup, seed_shuffle)
+    lut = complement_lut(dev)
+    view = d_bytes[:n_records * length].view(n_records, length)
+    col = torch.arange(length, device=dev)
+    for q in range(world):
+        mine = torch.nonzero(src_rank == q).flatten()
+        if mine.numel() == 0:
+            continue
+        base = fill(seed, q * n_records * length, half * length)[:half * length].view(half, length)     # rank q's base records
+        for c0 in range(0, mine.numel(), chunk):
+            c = mine[c0:c0 + chunk]
+            rows = torch.gather(base[src_j[c]], 1, (col.unsqueeze(0) + k[c].unsqueeze(1)) % length)
+            f = flip[c]
+            rows[f] = lut[rows[f].flip(1).long()]
+            view[half + c] = rows
+        del base
+    for c0 in range(0, length, 100):
+        view[:, c0:c0 + 100] = view[perm, c0:c0 + 100]
+
+
+def job_first_seen(n_records, length, world, rank, dev, seed_dup=43, seed_shuffle=44):
+    """Expected first-seen global index of every record of rank's shard over the WHOLE job (global index of position p
+    of rank q = q*n + p), from the planting decisions alone; also the job's number of distinct records."""
+    keys = [job_keys(n_records, length, world, q, dev, seed_dup, seed_shuffle) for q in range(world)]
+    allk = torch.cat(keys)
+    gidx = torch.arange(world * n_records, dtype=torch.int64, device=dev)
+    first = torch.full((world * n_records,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    first.scatter_reduce_(0, allk, gidx, "amin")
+    distinct = int((first != torch.iinfo(torch.int64).max).sum())
+    return first[keys[rank]], distinct, keys[rank]
+
+
+def job_check(fs, keep, n_records, length, world, rank, dev, seed_dup=43, seed_shuffle=44):
+    """A shard's first-seen indices and keep flags against job_first_seen(): (mismatching records, records of this shard whose
+    first-seen record lives on another rank, distinct records of the job, the shard's keys).  bench.py exits non-zero on a
+    mismatch; tests/test_uniq_sharded.py runs the same check under gloo, with broken exchanges as negative controls."""
+    exp_fs, distinct, keys = job_first_seen(n_records, length, world, rank, dev, seed_dup, seed_shuffle)
+    own = rank * n_records + torch.arange(n_records, dtype=torch.int64, device=dev)
+    wrong = int((fs.view(torch.int64) != exp_fs).sum()) + int((keep.bool() != (exp_fs == own)).sum())
+    cross = int(((exp_fs // n_records) != rank).sum())
+    return wrong, cross, distinct, keys

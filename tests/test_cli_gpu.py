@@ -258,3 +258,25 @@ def test_chunk_ring_geometry(tmp_path, slots, chunk_mb):
     assert r.returncode == 0, r.stderr
     assert r.stdout == want_u
     assert table.read_bytes() == want_t
+
+
+# ---- clap's accepted argument forms on the two GPU arms (src/commands.rs:6-14,112-149) ----
+@pytest.mark.parametrize("form", [
+    lambda i, o: ["uniq", i, "-ct4", "-o" + o],                  # combined shorts with a trailing valued one; -oFILE
+    lambda i, o: ["uniq", "-c", "-t=4", "-o=" + o, i],
+    lambda i, o: ["uniq", "--canon", "--threads=2", "--output=" + o, "--", i],
+    lambda i, o: ["-q", "uniq", "--norm", "-vt2", i, "-o", o],   # global -v / -q on either side of the subcommand
+    lambda i, o: ["uniq", "-qqc", i, "--output", o],
+])
+def test_clap_forms_uniq(form, tmp_path):
+    out = tmp_path / "out.fasta"
+    r = run(*form(fixture("repeated", "in.fasta"), str(out)))
+    assert r.returncode == 0 and r.stdout == b"" and r.stderr == b"", r.stderr
+    assert id_seq_map(out.read_bytes()) == id_seq_map(open(fixture("repeated", "out.fasta"), "rb").read())
+
+
+@pytest.mark.parametrize("args", [["canonicalize", "-q"], ["-v", "canonicalize", "-t1"], ["canonicalize", "--quiet", "-t", "2"], ["-vvv", "canonicalize"]])
+def test_clap_forms_canonicalize(args):
+    r = run(*args, fixture("multiple_sequences", "in.fasta"))
+    assert r.returncode == 0 and r.stderr == b""
+    assert id_seq_map(r.stdout) == id_seq_map(open(fixture("multiple_sequences", "out.fasta"), "rb").read())

@@ -166,3 +166,57 @@ def test_plain_stdin_keeps_the_sniffed_bytes():
     for data in (b">a\nA\n", b">ab\nACGT\n>c\nTT", b">x\n"):
         r = run("cat", stdin=data)
         assert (r.returncode, r.stdout) == (0, O.cli_cat(data)), (data, r.stderr)
+
+
+# ---- clap's accepted argument forms (src/commands.rs:6-14,93-180) on the host-only arms; the GPU arms share the parser
+# (tests/test_cli_gpu.py runs the same forms through canonicalize / uniq on the GPU box) ----
+CAT_IN = os.path.join(GOLDEN, "cat", "in.fasta")
+
+
+@pytest.mark.parametrize("form", [
+    lambda out: ["cat", CAT_IN, "-o" + out],                      # -oFILE
+    lambda out: ["cat", CAT_IN, "-o=" + out],                     # -o=FILE
+    lambda out: ["cat", CAT_IN, "--output=" + out],
+    lambda out: ["cat", "--output", out, CAT_IN],
+    lambda out: ["cat", "-o", out, "--", CAT_IN],                 # `--` ends the options
+    lambda out: ["-v", "cat", CAT_IN, "-o", out],                 # clap_verbosity_flag: global, before ...
+    lambda out: ["cat", "-q", CAT_IN, "-o", out],                 # ... or after the subcommand
+    lambda out: ["-vv", "cat", "-qo" + out, CAT_IN],              # repeated, and combined with a valued short
+    lambda out: ["--verbose", "cat", "--quiet", CAT_IN, "-o", out],
+])
+def test_clap_forms_on_a_host_arm(form, tmp_path):
+    out = str(tmp_path / "o.fasta")
+    r = run(*form(out))
+    assert (r.returncode, r.stdout, r.stderr) == (0, b"", b""), r.stderr
+    assert open(out, "rb").read() == O.cli_cat(open(CAT_IN, "rb").read())
+
+
+@pytest.mark.parametrize("args", [["rotate", "-b5"], ["rotate", "-b=5"], ["rotate", "--bases=5"], ["rotate", "-vb", "5"], ["rotate", "-qb5"]])
+def test_clap_forms_of_a_valued_short(args, tmp_path):
+    src = os.path.join(GOLDEN, "rotate_5", "in.fasta")
+    r = run(*args, src)
+    assert r.returncode == 0 and r.stdout == O.cli_rotate(open(src, "rb").read(), bases=5)
+
+
+@pytest.mark.parametrize("args,needle", [
+    (["cat", "-x"], b"unexpected argument '-x'"),
+    (["cat", "--frobnicate"], b"unexpected argument '--frobnicate'"),
+    (["cat", "a.fa", "b.fa"], b"unexpected argument 'b.fa'"),
+    (["cat", "-o"], b"requires a value"),
+    (["cat", "--quiet=3"], b"unexpected value"),
+    (["canonicalize", "-tx", "a.fa"], b"invalid value 'x' for '--threads <THREADS>'"),
+    (["uniq", "-ctfour", "a.fa"], b"invalid value 'four'"),
+    (["cat", "-c"], b"unexpected argument '-c'"),                # -c belongs to uniq only
+    (["rotate", "-b", "1", "-p", "0.5"], b"cannot be used with"),
+])
+def test_clap_errors_exit_2(args, needle):
+    r = run(*args)
+    assert r.returncode == 2 and r.stdout == b"" and needle in r.stderr, r.stderr
+
+
+def test_version_and_help():
+    for a in (["--version"], ["-V"]):
+        r = run(*a)
+        assert r.returncode == 0 and r.stdout.startswith(b"circkit ")
+    r = run("canonicalize", "--help")
+    assert r.returncode == 0 and b"USAGE" in r.stdout

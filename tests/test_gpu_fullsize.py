@@ -252,3 +252,77 @@ def test_bench_hash_only_lines(workload):
     assert line["cpu_baseline"]["gpu_output_matches"] is True
     if workload[1] == "uniq":
         assert line["unique_records"] == n // 2
+
+
+def test_config5_rank7_shard(ctx, O):
+    """BASELINE configs[4] as far as one GPU can run it: the shard rank 7 of `bench.py --gpus 8` takes -- 12,500,000 records x
+    1 kb at global record index 87,500,000 (base offsets up to 10^11 in the counter-based generator, 12.5 GB in + 12.5 GB
+    out in ONE batch).  Oracle bytes on a 20k slice whose INPUT is regenerated on the host at the same global base (so the
+    device generator's 64-bit base arithmetic is pinned too), two slices deep inside the shard, idempotence and invariance
+    under reverse complement + rotation over the whole shard (lib/src/canonicalize.rs:54-63, :124-132, :216-231)."""
+    import torch
+    from circkit_amd import workloads as W
+    N, L, rank = 12_500_000, 1000, 7
+    dev = torch.device("cuda", 0)
+    x, off = W.fixed_length(ctx, dev, N, L, 42, first_record=rank * N)
+    c1 = torch.full_like(x, 0x3F)
+    ctx.canonicalize_batch_device(x, off, N, out_bytes=c1)
+    assert ctx.batch_status() == 0
+    assert ctx.last_batch_mode() == 1
+    assert bool((c1[N * L:] == 0x3F).all())
+    h_off = np.arange(20_001, dtype=np.uint64) * np.uint64(L)
+    for r0 in (0, 6_250_000, N - 20_000):             # first, middle and last records of the shard
+        host_in = O.synth_fill(42, (rank * N + r0) * L, 20_000 * L)
+        assert np.array_equal(host_in, x[r0 * L:(r0 + 20_000) * L].cpu().numpy()), "device generator differs from the host's at the global base"
+        exp, _ = O.canonicalize_batch(host_in, h_off, True, False, threads=8)
+        assert np.array_equal(c1[r0 * L:(r0 + 20_000) * L].cpu().numpy(), exp)
+    c2 = torch.empty_like(x)
+    ctx.canonicalize_batch_device(c1, off, N, out_bytes=c2)
+    assert ctx.batch_status() == 0
+    assert torch.equal(c1[:N * L], c2[:N * L]), "not idempotent"
+    del c2
+    y = W.revcomp_rotate_csr(x, off, N, dev, shift=137)
+    c3 = torch.empty_like(x)
+    ctx.canonicalize_batch_device(y, off, N, out_bytes=c3)
+    assert ctx.batch_status() == 0
+    assert torch.equal(c1[:N * L], c3[:N * L]), "canonical form changed under reverse complement + rotation"
+
+
+def test_job_wide_uniq_workload_on_one_gpu(ctx, O):
+    """The multi-rank `uniq` workload of bench.py (workloads.plant_job_duplicates: a duplicate's original lives on ANY rank)
+    with all 8 shards built and hashed one after the other on this GPU: the device hashes of the whole job, resolved by the
+    oracle's first-seen map, equal the expectation bench.py checks every rank against (workloads.job_first_seen), most
+    first-seen records live on another rank, and every shard's first records pass the oracle slice (bytes, XXH3, and canonical
+    form == that of the base record its key names)."""
+    import torch
+    import bench
+    from circkit_amd import workloads as W
+    world, N, L = 8, 40_000, 1000
+    dev = torch.device("cuda", 0)
+
+    def fill(seed, first_base, n_bases):
+        buf = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+        ctx.synth_fill_device(seed, first_base, n_bases, buf)
+        return buf
+    job_h = []
+    for rank in range(world):
+        x, off = W.fixed_length(ctx, dev, N, L, 42, rank * N)
+        W.plant_job_duplicates(fill, x, N, L, dev, rank, world)
+        out = torch.empty_like(x)
+        hs = torch.empty(N, dtype=torch.int64, device=dev)
+        ctx.canonicalize_batch_device(x, off, N, out_bytes=out, out_xxh3=hs)
+        assert ctx.batch_status() == 0
+        job_h.append(hs.cpu().numpy().astype(np.uint64))
+        keys = W.job_keys(N, L, world, rank, dev)
+
+        class A:
+            hash_only = False
+        assert bench.job_oracle_slice(np, torch, A, N, L, rank, x, {"out": out, "hash": hs}, keys) is None
+    fs = O.uniq_first_seen(np.concatenate(job_h)).astype(np.int64)
+    cross = 0
+    for rank in range(world):
+        exp, distinct, _ = W.job_first_seen(N, L, world, rank, dev)
+        assert distinct == world * (N // 2)
+        assert np.array_equal(exp.cpu().numpy(), fs[rank * N:(rank + 1) * N])
+        cross += int(((exp // N) != rank).sum())
+    assert cross > world * N // 4

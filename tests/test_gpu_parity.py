@@ -303,6 +303,37 @@ def test_long_record_scratch_limit_is_reported(O):
     c.close()
 
 
+def test_refused_record_in_a_hash_only_batch_is_a_clean_status(O):
+    """a hash-only batch (views, no bytes) with a record no stage can take.  The ctx's view array still holds what
+    an earlier batch left at that index -- here the rotation of a 6 Mb record, far beyond the refused record's 4.5 Mb, reverse
+    strand -- and the xxh3 pass must not address the payload with it: status 1 (CIRCKIT_ERR_TOO_LONG), no fault, every other
+    record's hash right."""
+    import torch
+    import circkit_amd
+    from tests import seqsets
+    c = circkit_amd.Context(0)
+    dev = torch.device("cuda", 0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(61)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    small = seqsets.random_mixed(88, 20, 100, 240)
+    # minimal rotation of the reverse strand starts ~5.9 Mb into it: a run of T near the record's start
+    big = acgt[rng.integers(0, 4, 6_000_000)].copy()
+    big[100_000:100_040] = ord("T")
+    for seqs, limit, want in ((small + [big.tobytes()], None, 0), (small + [acgt[rng.integers(0, 4, 4_500_000)].tobytes()], 1 << 20, 1)):
+        if limit:
+            c.set_long_record_scratch(limit)
+        data, offs = seqsets.pack(seqs)
+        d_bytes = torch.from_numpy(data).to(dev)
+        d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        d_hash = torch.zeros(len(seqs), dtype=torch.int64, device=dev)
+        c.canonicalize_batch_device(d_bytes, d_off, len(seqs), out_xxh3=d_hash)
+        assert c.batch_status() == want
+        _, exp_h = O.canonicalize_batch(data[:int(offs[-2])], offs[:-1], False, True, threads=8)
+        assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64)[:-1], exp_h)
+    c.close()
+
+
 def test_zipf_mixed_lengths_config4_shape(ctx, O):
     """BASELINE config 4 shape at a size the oracle finishes in seconds: 3000 records, L ~ 1/L on [200, 20000]."""
     rng = np.random.default_rng(45)

@@ -139,3 +139,76 @@ def test_single_process_first_seen():
     assert fs.tolist() == [100, 101, 100, 103, 101, 100, 106, 106]
     assert keep.tolist() == [True, True, False, True, False, False, True, False]
     assert (O.uniq_first_seen(h) + 100).tolist() == fs.tolist()
+
+
+# ---- the bench's multi-rank `uniq` workload (config 3 over a whole job) and its check, under gloo at world 8 ---------------
+def _job_worker(rank, world, port, n, length, q, broken):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from circkit_amd import uniq, workloads as W
+    from oracle import oracle as O
+    dev = torch.device("cpu")
+    fill = lambda seed, first, nb: torch.from_numpy(O.synth_fill(seed, first, nb).copy())
+    shard = fill(42, rank * n * length, n * length)
+    W.plant_job_duplicates(fill, shard, n, length, dev, rank, world)
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(length)
+    _, h = O.canonicalize_batch(shard.numpy(), offs, False, True)
+    hashes = torch.from_numpy(h.astype(np.int64))
+    if broken == "local":
+        # an "exchange" that returns every rank's own answer: what a job-wide check must catch (missing #1)
+        fs, keep = _local_first_seen(hashes, rank * n)
+    else:
+        if broken == "back":
+            # the answers' way back delivered out of order (circkit_amd/uniq.py, the second all-to-all of the rows branch)
+            real, calls = dist.all_to_all_single, [0]
+
+            def shuffled(out, inp, *a, **kw):
+                r = real(out, inp, *a, **kw)
+                calls[0] += 1
+                if calls[0] == 3 and out.numel() > 1:
+                    out.copy_(out.roll(1))
+                return r
+            uniq.dist.all_to_all_single = shuffled
+        fs, keep = uniq.first_seen(RowsTable(), hashes, base_index=rank * n, exchange="partition")
+    wrong, cross, distinct, _ = W.job_check(fs, keep, n, length, world, rank, dev)
+    q.put((rank, wrong, cross, distinct, int(keep.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _local_first_seen(hashes, base):
+    from oracle import oracle as O
+    fs = torch.from_numpy(O.uniq_first_seen(hashes.numpy().astype(np.uint64)).astype(np.int64)) + base
+    return fs, fs == torch.arange(base, base + hashes.numel(), dtype=torch.int64)
+
+
+@pytest.mark.parametrize("broken", [None, "local", "back"])
+def test_job_wide_duplicates_at_world_8(broken):
+    """bench.py --workload uniq --gpus 8 in small: every rank plants duplicates of base records of ALL ranks
+    (workloads.plant_job_duplicates, the generator regenerates any rank's records locally), hashes its shard, runs the
+    exchange, and checks every record against the job-wide expectation (workloads.job_check -- the function bench.py exits
+    non-zero on).  Negative controls: an exchange that answers locally, and answers that come back out of order, must fail
+    the check (src/uniq.rs:47-48: first record of each hash over the WHOLE input)."""
+    world, n, length = 8, 240, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, n, length, q, broken)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    wrong = sum(r[1] for r in res)
+    cross = sum(r[2] for r in res)
+    kept = sum(r[4] for r in res)
+    assert all(r[3] == world * (n // 2) for r in res)
+    assert cross > world * n // 4                     # most duplicates' originals live on another rank
+    if broken is None:
+        assert wrong == 0 and kept == world * (n // 2)
+    else:
+        assert wrong > 0
+        if broken == "local":
+            assert kept != world * (n // 2)           # the kept count alone catches this one only because owners are cross-rank
