@@ -10,12 +10,16 @@ _SO = os.path.join(_HERE, "libcanon_emu.so")
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "circkit_amd", "csrc")
 
 
+SANITIZE = ["-fsanitize=undefined,bounds", "-fno-sanitize-recover=undefined,bounds"]
+
+
 def build():
     srcs = [os.path.join(_HERE, "emu.cpp"), os.path.join(_HERE, "wave_prims_emu.h")] + \
         [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
     if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-o", _SO,
-                               os.path.join(_HERE, "emu.cpp")])
+        # UBSan + bounds checks compiled in, no recovery: undefined shifts, misaligned or out-of-bounds accesses in the kernel
+        # source abort the test process (sanitizers on the CPU build only -- the GPU pool offers none)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared"] + SANITIZE + ["-o", _SO, os.path.join(_HERE, "emu.cpp")])
     return _SO
 
 
