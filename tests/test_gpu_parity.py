@@ -305,13 +305,14 @@ def test_long_record_scratch_limit_is_reported(O):
 
 def test_refused_record_in_a_hash_only_batch_is_a_clean_status(O):
     """a hash-only batch (views, no bytes) with a record no stage can take.  The ctx's view array still holds what
-    an earlier batch left at that index -- here the rotation of a 6 Mb record, far beyond the refused record's 4.5 Mb, reverse
-    strand -- and the xxh3 pass must not address the payload with it: status 1 (CIRCKIT_ERR_TOO_LONG), no fault, every other
-    record's hash right."""
+    an earlier batch left at that index -- here the rotation (~5.9M, reverse strand) of a 6 Mb record, beyond the length of the
+    3 Mb record that is then refused (arbitrary bytes: two stored strands do not fit the 2 MiB scratch) -- and the xxh3 pass
+    must not address the payload with it: status 1 (CIRCKIT_ERR_TOO_LONG), no fault, every other record's hash right."""
     import torch
     import circkit_amd
     from tests import seqsets
     c = circkit_amd.Context(0)
+    c.set_long_record_scratch(2 << 20)               # pure-ACGT records up to ~8.4 Mb; byte-alphabet records far less
     dev = torch.device("cuda", 0)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(61)
@@ -320,9 +321,8 @@ def test_refused_record_in_a_hash_only_batch_is_a_clean_status(O):
     # minimal rotation of the reverse strand starts ~5.9 Mb into it: a run of T near the record's start
     big = acgt[rng.integers(0, 4, 6_000_000)].copy()
     big[100_000:100_040] = ord("T")
-    for seqs, limit, want in ((small + [big.tobytes()], None, 0), (small + [acgt[rng.integers(0, 4, 4_500_000)].tobytes()], 1 << 20, 1)):
-        if limit:
-            c.set_long_record_scratch(limit)
+    odd = np.frombuffer(b"ACGTXYZ", dtype=np.uint8)[rng.integers(0, 7, 3_000_000)]
+    for seqs, want in ((small + [big.tobytes()], 0), (small + [odd.tobytes()], 1)):
         data, offs = seqsets.pack(seqs)
         d_bytes = torch.from_numpy(data).to(dev)
         d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
