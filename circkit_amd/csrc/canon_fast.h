@@ -31,17 +31,17 @@ CK_DEV uint32_t fast2_locate(uint32_t E, uint32_t En, uint64_t hm, uint32_t M, u
     const uint32_t l = (uint32_t)ffs64(hm);                                 // hm != 0: some valid word owns the minimum
     const uint32_t k = lshr64(readlane(E, l), readlane(En, l), shv);
     const uint32_t left = n - 16 * l;                                       // valid positions in word l (>= 1)
-    uint32_t pm = (uint32_t)ballot(k == M) & (0xFFFFu >> (16 - (left < 16 ? left : 16)));
-    uint32_t cnt = (uint32_t)popc64(pm);
-    uint32_t pos = 16 * l + (uint32_t)ffs64_or_neg(pm);                     // pm == 0: garbage, and cnt says so
-    if (popc64(hm) != 1) {                                                  // rare
+    uint32_t pm = (uint32_t)ballot(k == M) & low_mask16(left);
+    uint32_t cnt = (uint32_t)popc32(pm);
+    uint32_t pos = 16 * l + (uint32_t)ffs32_or_neg(pm);                     // pm == 0: garbage, and cnt says so
+    if ((uint32_t)popc64(hm) != 1u) {                                       // rare
         hm &= hm - 1;
         const uint32_t l2 = (uint32_t)ffs64(hm);
         const uint32_t k2 = lshr64(readlane(E, l2), readlane(En, l2), shv);
         const uint32_t left2 = n - 16 * l2;
-        const uint32_t pm2 = (uint32_t)ballot(k2 == M) & (0xFFFFu >> (16 - (left2 < 16 ? left2 : 16)));
-        cnt += (uint32_t)popc64(pm2) + ((hm & (hm - 1)) ? 2u : 0u);         // a third hit lane: give up
-        if (pm == 0) pos = 16 * l2 + (uint32_t)ffs64_or_neg(pm2);
+        const uint32_t pm2 = (uint32_t)ballot(k2 == M) & low_mask16(left2);
+        cnt += (uint32_t)popc32(pm2) + ((hm & (hm - 1)) ? 2u : 0u);         // a third hit lane: give up
+        if (pm == 0) pos = 16 * l2 + (uint32_t)ffs32_or_neg(pm2);
     }
     unique = cnt == 1;
     return pos;
@@ -200,20 +200,23 @@ CK_DEV uint32_t word_min_key16(uint32_t cur, uint32_t nxt)
 // fast2_locate() on the 16-bit prefixes
 CK_DEV uint32_t fast2_locate16(uint32_t E, uint32_t En, uint64_t hm, uint32_t M16, uint32_t n, uint32_t shv, bool& unique)
 {
+    // (scalar instruction count matters here -- the streaming kernel issues about as many scalar as vector instructions per
+    // record: the position mask is (1 << min(left, 16)) - 1 = s_min + s_bfm, the first set bit one s_ff1 that yields -1 for an
+    // empty mask, the lane count a 32-bit compare)
     const uint32_t l = (uint32_t)ffs64(hm);
     const uint32_t k = lshr64(readlane(E, l), readlane(En, l), shv) >> 16;
     const uint32_t left = n - 16 * l;
-    uint32_t pm = (uint32_t)ballot(k == M16) & (0xFFFFu >> (16 - (left < 16 ? left : 16)));
-    uint32_t cnt = (uint32_t)popc64(pm);
-    uint32_t pos = 16 * l + (uint32_t)ffs64_or_neg(pm);
-    if (popc64(hm) != 1) {                                                  // rare
+    uint32_t pm = (uint32_t)ballot(k == M16) & low_mask16(left);
+    uint32_t cnt = (uint32_t)popc32(pm);
+    uint32_t pos = 16 * l + (uint32_t)ffs32_or_neg(pm);
+    if ((uint32_t)popc64(hm) != 1u) {                                       // rare
         hm &= hm - 1;
         const uint32_t l2 = (uint32_t)ffs64(hm);
         const uint32_t k2 = lshr64(readlane(E, l2), readlane(En, l2), shv) >> 16;
         const uint32_t left2 = n - 16 * l2;
-        const uint32_t pm2 = (uint32_t)ballot(k2 == M16) & (0xFFFFu >> (16 - (left2 < 16 ? left2 : 16)));
-        cnt += (uint32_t)popc64(pm2) + ((hm & (hm - 1)) ? 2u : 0u);
-        if (pm == 0) pos = 16 * l2 + (uint32_t)ffs64_or_neg(pm2);
+        const uint32_t pm2 = (uint32_t)ballot(k2 == M16) & low_mask16(left2);
+        cnt += (uint32_t)popc32(pm2) + ((hm & (hm - 1)) ? 2u : 0u);
+        if (pm == 0) pos = 16 * l2 + (uint32_t)ffs32_or_neg(pm2);
     }
     unique = cnt == 1;
     return pos;
@@ -232,6 +235,7 @@ struct FastShape {
     uint32_t ext_lane;              // t - ceil(n/16): source word of the extension
     uint32_t rc_lane, rc_sh;        // reverse strand: source word and funnel shift
     uint32_t out_o;                 // byte offset of this lane's 16 output bytes
+    uint32_t inv;                   // ~0 in the lanes past the record's last word (their scan results must lose every minimum), else 0
 };
 CK_DEV void fast_shape(FastShape& sh, uint32_t n)
 {
@@ -246,6 +250,7 @@ CK_DEV void fast_shape(FastShape& sh, uint32_t n)
     // every lane stores a full 16 bytes: the last lane's window is pulled back to end exactly at n, so it overlaps
     // its neighbour's with identical bytes -- one store instruction, no partial-store branches
     sh.out_o = 16 * t + 16 <= n ? 16 * t : n - 16;
+    sh.inv = t < nwv ? 0u : ~0u;
 }
 
 // HASH = false compiles the fused XXH3 out; AUX = false compiles out what only some callers ask for (rotation index
@@ -300,7 +305,10 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
     uint32_t idx = 0, iF = 0, decided = 16;                // symbols of the winner's key that decided (NM)
     if constexpr (K16) {
         decided = 8;
-        uint32_t mF = valid ? word_min_key16(F, Fn) : 0xFFFFu, mC = valid ? word_min_key16(C, Cn) : 0xFFFFu;
+        // every lane scans (a VALU instruction costs the same with any exec mask); the lanes past the record are ORed out of
+        // the minimum instead of being branched around: `valid ? scan : 0xFFFF` compiled to two exec-mask regions
+        // (s_and_saveexec / s_cbranch_execz / s_or: 6 scalar instructions + 2 branches per record)
+        uint32_t mF = word_min_key16(F, Fn) | sh.inv, mC = word_min_key16(C, Cn) | sh.inv;
         uint32_t MF, MC;
         wave_min2_u32(mF, mC, MF, MC);
         fwd = fwd_only || MF < MC;

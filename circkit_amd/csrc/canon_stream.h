@@ -154,7 +154,13 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         const uint32_t gf = g + D * nblocks, gfc = gf < n_staged ? gf : 0;
         const uint32_t ra = g * C::GROUP + C::RPW * w;
         uint64_t s, e, o0, o1, o2;
+#ifdef CK_EXP_FIXED1000
+        // EXPERIMENT build only (tools/probe_variants.py): every record 1000 bytes, offsets computed instead of loaded -- an upper
+        // bound of what leaner scalar bookkeeping at the head of the loop could buy
+        s = (uint64_t)gfc * C::GROUP * 1000; e = s + C::GROUP * 1000; o0 = (uint64_t)ra * 1000; o1 = o0 + 1000; o2 = o1 + 1000;
+#else
         sload_group<(int)C::GROUP>(a.offsets + (uint64_t)gfc * C::GROUP, a.offsets + ra, s, e, o0, o1, o2);
+#endif
         const uint32_t bf = bi ? bi - 1 : C::NBUF - 1;                     // the buffer freed by the previous iteration
 #ifdef CK_DEBUG_POISON
         stream_poison<C>(ring + bf * C::BUF_DW);

@@ -249,6 +249,20 @@ CK_DEV void vmem_wait()
 }
 CK_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }   // v_sad_u8
 CK_DEV int ffs64_or_neg(uint64_t v) { return __builtin_ffsll((long long)v) - 1; }      // s_ff1_i32_b64: -1 for 0
+// index of the lowest set bit of a wave-uniform word, -1 for 0: ONE s_ff1_i32_b32 (through __builtin_ffs the compiler adds a
+// compare and two selects for the zero case the instruction already answers)
+CK_DEV int ffs32_or_neg(uint32_t v)
+{
+    int r;
+    asm("s_ff1_i32_b32 %0, %1" : "=s"(r) : "s"(v));
+    return r;
+}
+// the low min(left, 16) bits set (left wave-uniform): s_min_u32 + s_bfm_b32
+CK_DEV uint32_t low_mask16(uint32_t left)
+{
+    const uint32_t l16 = left < 16u ? left : 16u;
+    return (1u << l16) - 1u;
+}
 typedef uint32_t ck_u32x4v __attribute__((ext_vector_type(4)));
 CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b)
 {

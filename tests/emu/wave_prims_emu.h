@@ -136,6 +136,8 @@ CK_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t acc)
     return acc;
 }
 CK_DEV int ffs64_or_neg(uint64_t v) { return v ? __builtin_ctzll(v) : -1; }
+CK_DEV int ffs32_or_neg(uint32_t v) { return v ? __builtin_ctz(v) : -1; }
+CK_DEV uint32_t low_mask16(uint32_t left) { return (1u << (left < 16u ? left : 16u)) - 1u; }
 template <int N>
 CK_DEV void vmem_wait() {}
 CK_DEV void sload_u64x2(const uint64_t* p, uint64_t& a, uint64_t& b) { a = p[0]; b = p[1]; }

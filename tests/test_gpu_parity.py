@@ -306,13 +306,13 @@ def test_long_record_scratch_limit_is_reported(O):
 def test_refused_record_in_a_hash_only_batch_is_a_clean_status(O):
     """a hash-only batch (views, no bytes) with a record no stage can take.  The ctx's view array still holds what
     an earlier batch left at that index -- here the rotation (~5.9M, reverse strand) of a 6 Mb record, beyond the length of the
-    3 Mb record that is then refused (arbitrary bytes: two stored strands do not fit the 2 MiB scratch) -- and the xxh3 pass
+    3 Mb record that is then refused (arbitrary bytes: two stored strands do not fit the 4 MiB scratch) -- and the xxh3 pass
     must not address the payload with it: status 1 (CIRCKIT_ERR_TOO_LONG), no fault, every other record's hash right."""
     import torch
     import circkit_amd
     from tests import seqsets
     c = circkit_amd.Context(0)
-    c.set_long_record_scratch(2 << 20)               # pure-ACGT records up to ~8.4 Mb; byte-alphabet records far less
+    c.set_long_record_scratch(4 << 20)               # pure-ACGT records up to ~16 Mb (strand + tie bitmask); byte-alphabet records ~2 Mb
     dev = torch.device("cuda", 0)
     c.set_stream(torch.cuda.current_stream().cuda_stream)
     rng = np.random.default_rng(61)
