@@ -22,6 +22,13 @@ namespace ck {
 // ROWS == 2 build also takes records of 1009..2032 bases (fast_canon2, two packed words per lane); it is a separate
 // build because carrying that path costs the one-word path ~12 % more instructions (measured), so launch_canon picks
 // it only for batches whose mean record length lies in that range.
+// The iteration's scalar loads of the offsets are cold misses all the way to HBM (80 MB per 10M-record batch, every line used
+// by one iteration of one workgroup) and every wave of the workgroup waits for them right behind the barrier, before anything
+// else can be issued.  With CK_STREAM_TOUCH the line(s) the NEXT iteration's loads will ask for are fetched one iteration
+// ahead by an LDS-DMA into a dump area (wave_prims.h glds4_touch): the scalar loads then find them in the L2.
+#ifndef CK_STREAM_TOUCH
+#define CK_STREAM_TOUCH 1
+#endif
 template <int WPB_, int NBUF_, int RPW_ = 2, int ROWS_ = 1>
 struct StreamCfg {
     static constexpr int WPB = WPB_, RPW = RPW_, NBUF = NBUF_;
@@ -33,7 +40,8 @@ struct StreamCfg {
     // ring, then the decode table, the deferral counter and (ROWS == 2) 1 KiB of padding: a record's lanes past its
     // end read up to 63 / 127 chunks beyond the image (never used), which for the last buffer lands in the table and
     // the padding
-    static constexpr uint32_t LDS_DW = NBUF * BUF_DW + FAST_LUT_DW + 4 + (ROWS == 2 ? 256 : 0);
+    static constexpr uint32_t PF = CK_STREAM_TOUCH;             // 1: every iteration touches the offsets it will load two iterations on
+    static constexpr uint32_t LDS_DW = NBUF * BUF_DW + FAST_LUT_DW + 4 + (ROWS == 2 ? 256 : 0) + 64 * PF;     // (+ the touches' dump area, last)
 };
 
 // 1 KiB slot of the image that DMA instruction i of wave w fills: the first RPW instructions of every wave tile the
@@ -53,20 +61,44 @@ struct StreamGroup {
 // (wave*RPW + i)*64 + lane of the image; c16[i] = 16 * that chunk index, precomputed), whatever the group looks like
 // -- the vmcnt bookkeeping of the loop depends on it.  Lanes past the span re-fetch its last chunk; unstaged groups
 // fetch the offsets array (always readable).  All but the per-lane clamp is scalar work.
+// Per-kernel constants of the DMA addressing: the payload pointer pulled back to a 16-byte boundary, and by how much.
+struct StreamBase {
+    const uint8_t* abase;     // a.bytes - mis
+    uint32_t mis;             // (uintptr_t)a.bytes & 15
+    uint32_t misaligned;      // mis != 0 ? 1 : 0
+};
+CK_DEV StreamBase stream_base(const CanonArgs& a)
+{
+    StreamBase b;
+    b.mis = (uint32_t)(uintptr_t)a.bytes & 15u;
+    b.abase = a.bytes - b.mis;
+    b.misaligned = b.mis != 0 ? 1u : 0u;
+    return b;
+}
+// The scalar side is written for instruction count (the hash builds of the streaming kernel are bound by instruction issue,
+// scalar and vector alike; tools/probe_variants.py): everything is relative to the ALIGNED pointer, the three conditions are
+// folded into one word that must be zero, the 64-bit compares are done on the halves (there is no s_cmp_lt_u64, the compiler
+// moves them to the vector unit), and the lane offset is clamped against a scalar that is already zero for an unstaged group.
 template <class C>
-CK_DEV StreamGroup stream_issue(const CanonArgs& a, bool in_range, uint64_t s, uint64_t e, uint32_t* buf, const uint32_t (&c16)[C::DPW])
+CK_DEV StreamGroup stream_issue(const CanonArgs& a, const StreamBase& sb, uint32_t out_of_range, uint64_t s, uint64_t e, uint32_t* buf, const uint32_t (&c16)[C::DPW])
 {
     static_assert((C::SPAN & (C::SPAN - 1)) == 0, "image size must be a power of two");
-    const uint32_t mis = ((uint32_t)(uintptr_t)a.bytes + (uint32_t)s) & 15;
-    const uint64_t base = s - mis;
-    const uint64_t nb1 = e - base - 1;                // image bytes - 1; wraps to huge for an empty span
+    const uint64_t s1 = s + sb.mis;                   // the group's first byte, counted from abase
+    const uint32_t base_lo = (uint32_t)s1 & ~15u, s1_hi = (uint32_t)(s1 >> 32);
+    const uint64_t base1 = ((uint64_t)s1_hi << 32) | base_lo;
+    const uint64_t nb1 = e + sb.mis - base1 - 1;      // image bytes - 1; wraps to huge for an empty span
+    // not staged: a group whose first chunk would start before the payload (unaligned d_bytes: base1 == 0 reads the `mis` bytes
+    // in front of it), empty or oversized spans (and, by the caller, the batch's last group: its final chunk would read past
+    // the payload)
+    // (flags as 0 / 1 words, not bools: a bool with two uses is materialised as a lane mask and its 0 / 1 value comes back
+    // through the vector unit, taking everything behind it along)
+    uint32_t bad = (uint32_t)(nb1 >> 32) | ((uint32_t)nb1 / C::SPAN) | out_of_range;
+    bad |= (base_lo | s1_hi) == 0 ? sb.misaligned : 0u;
     StreamGroup grp;
-    grp.base_lo = (uint32_t)base;
-    // not staged: a group whose first chunk would start before the payload (unaligned d_bytes), empty or oversized
-    // spans (and, by the caller, the batch's last group: its final chunk would read past the payload)
-    grp.ok = in_range && ((s >> 4) != 0 || (uint32_t)s >= mis) && nb1 / C::SPAN == 0;
+    grp.ok = bad == 0;
+    grp.base_lo = base_lo - sb.mis;                   // low 32 bits of the image's first byte as an offset into a.bytes
     const uint32_t last16 = grp.ok ? (uint32_t)nb1 & ~15u : 0u;
-    const uint8_t* src = grp.ok ? a.bytes + base : (const uint8_t*)a.offsets;
+    const uint8_t* src = grp.ok ? sb.abase + base1 : (const uint8_t*)a.offsets;
     // DMA i of wave w covers chunks (i*WPB*RPW + w*RPW + i%RPW...) -- laid out so that the first RPW instructions of all
     // waves together cover the first half of the image: groups of records up to 1 KiB (the common case) need only
     // those, and the second half is skipped.  Allowed because with one group in flight (NBUF == 2) no vmcnt wait
@@ -115,6 +147,10 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
     static_assert(!GH || (HASH && C::RPW == 1 && C::GROUP == 16), "the group merger takes 16 records, one per wave");
     constexpr int D = C::NBUF - 1;                    // groups in flight
+    // the touches pay in the builds with the fused XXH3, which are bound by instruction issue (same box, 10M x 1 kb: bytes + hash
+    // 4.16 -> 4.05 ms); the bytes-only build sits on the memory system and LOSES when its loads go out earlier (3.60 -> 4.00 ms
+    // with the touches, 3.60 -> 3.79 with offsets that need no load at all: tools/probe_variants.py)
+    constexpr int PF = HASH ? (int)C::PF : 0;
     const uint32_t N = (uint32_t)a.n_records, n_groups = (N + C::GROUP - 1) / C::GROUP;
     if (N == 0) return;
     const uint32_t n_staged = n_groups - 1;           // the batch's last group is never staged
@@ -135,6 +171,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
 #pragma unroll
     for (int i = 0; i < C::DPW; ++i) c16[i] = (stream_slot<C>(w, (uint32_t)i) * 64 + t) * 16;
     // ring state in scalars: q[0] = the group being processed, q[1..D-1] = the ones in flight behind it
+    const StreamBase sb = stream_base(a);
     StreamGroup q[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -144,29 +181,54 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
 #ifdef CK_DEBUG_POISON
         stream_poison<C>(ring + d * C::BUF_DW);
 #endif
-        q[d] = stream_issue<C>(a, g < n_staged, s, e, ring + d * C::BUF_DW, c16);
+        q[d] = stream_issue<C>(a, sb, g < n_staged ? 0u : 1u, s, e, ring + d * C::BUF_DW, c16);
     }
     vmem_wait<(D - 1) * C::DPW>();                    // the first group's DMAs; the later ones may still fly
     block_barrier();
-    uint32_t bi = 0, it = 0;                          // buffer index of q[0]; iteration count
+    // loop-carried scalars, advanced by addition (no index -> address arithmetic per iteration): the offsets of the group to
+    // prefetch and of this wave's record(s), the ring position of q[0] and of the image freed by the previous iteration
+    const uint64_t stride = (uint64_t)nblocks * C::GROUP;
+    const uint64_t* p_grp = a.offsets + ((uint64_t)block + (uint64_t)D * nblocks) * C::GROUP;
+    const uint64_t* p_rec = a.offsets + ((uint64_t)block * C::GROUP + C::RPW * w);
+    uint32_t gf = block + D * nblocks, ra = block * C::GROUP + C::RPW * w;
+    uint32_t img_dw = 0, free_dw = (C::NBUF - 1) * C::BUF_DW, it = 0;
+    const uint32_t pf_off = (t >> 5) * (C::GROUP * 8);
+    uint32_t oor = (n_staged - 1u - gf) >> 31;                  // 1: the group to prefetch does not exist (both < 2^28)
+#ifdef CK_EXP_UNIFORM
+    uint64_t exp_a, exp_b;
+    sload_2u64(a.offsets, a.offsets + 1, exp_a, exp_b);
+    const uint32_t exp_len = (uint32_t)(exp_b - exp_a);
+#endif
     for (uint32_t g = block; g < n_staged; g += nblocks, ++it) {
         // one scalar round trip per iteration: the span of the group to prefetch and this wave's record offsets
-        const uint32_t gf = g + D * nblocks, gfc = gf < n_staged ? gf : 0;
-        const uint32_t ra = g * C::GROUP + C::RPW * w;
         uint64_t s, e, o0, o1, o2;
-#ifdef CK_EXP_FIXED1000
+#ifdef CK_EXP_UNIFORM
+        // EXPERIMENT build only: offsets of a batch of equal-length records computed from the (runtime) length
+        { const uint64_t L = exp_len; s = (uint64_t)(oor ? 0 : gf) * C::GROUP * L; e = s + C::GROUP * L; o0 = (uint64_t)ra * L; o1 = o0 + L; o2 = o1 + L; }
+#elif defined(CK_EXP_FIXED1000)
         // EXPERIMENT build only (tools/probe_variants.py): every record 1000 bytes, offsets computed instead of loaded -- an upper
         // bound of what leaner scalar bookkeeping at the head of the loop could buy
-        s = (uint64_t)gfc * C::GROUP * 1000; e = s + C::GROUP * 1000; o0 = (uint64_t)ra * 1000; o1 = o0 + 1000; o2 = o1 + 1000;
+        s = (uint64_t)(oor ? 0 : gf) * C::GROUP * 1000; e = s + C::GROUP * 1000; o0 = (uint64_t)ra * 1000; o1 = o0 + 1000; o2 = o1 + 1000;
 #else
-        sload_group<(int)C::GROUP>(a.offsets + (uint64_t)gfc * C::GROUP, a.offsets + ra, s, e, o0, o1, o2);
+        sload_group<(int)C::GROUP>(oor ? a.offsets : p_grp, p_rec, s, e, o0, o1, o2);
 #endif
-        const uint32_t bf = bi ? bi - 1 : C::NBUF - 1;                     // the buffer freed by the previous iteration
 #ifdef CK_DEBUG_POISON
-        stream_poison<C>(ring + bf * C::BUF_DW);
+        stream_poison<C>(ring + free_dw);
 #endif
-        const StreamGroup fut = stream_issue<C>(a, gf < n_staged, s, e, ring + bf * C::BUF_DW, c16);
-        const uint32_t* img = ring + bi * C::BUF_DW;
+#ifdef CK_EXP_DMA_SLEEP
+        if (!HASH) __builtin_amdgcn_s_sleep(CK_EXP_DMA_SLEEP);      // EXPERIMENT: the bytes-only build loses when its loads go out earlier -- does it gain when they go out later?
+#endif
+        const StreamGroup fut = stream_issue<C>(a, sb, oor, s, e, ring + free_dw, c16);
+        // the next iteration's group to prefetch
+        gf += nblocks;
+        p_grp += stride;
+        oor = (n_staged - 1u - gf) >> 31;
+        if constexpr (PF) {
+            // the offsets the next iteration loads: the span of that group -- its first offset (lanes 0..31) and the one behind
+            // its last (lanes 32..63: the next 128 bytes) -- which are also the lines of this wave's record two iterations on
+            glds4_touch(ring + (C::LDS_DW - 64), oor ? a.offsets : p_grp, pf_off);
+        }
+        const uint32_t* img = ring + img_dw;
         uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + w) * GH_STRIDE_DW : nullptr;
         if (GH) group_hash_invalidate(slot);
 #pragma unroll
@@ -252,15 +314,20 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
 #ifdef CK_DEBUG_POISON_BREAK
         vmem_wait<63>();                                  // negative control of the poison guard: no wait at all -- the count must NOT stay zero
 #else
-        if (!stores) vmem_wait<(D - 1) * C::DPW>();
-        else if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + C::RPW>();
-        else vmem_wait<(D - 1) * C::DPW + D * C::RPW>();
+        // (touches: one per iteration, issued right behind the iteration's DMAs -- D of them are younger than the DMAs waited
+        // for, one at least while the next group is still one of the prologue's)
+        if (!stores) { if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + PF>(); else vmem_wait<(D - 1) * C::DPW + D * PF>(); }
+        else if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + C::RPW + PF>();
+        else vmem_wait<(D - 1) * C::DPW + D * C::RPW + D * PF>();
 #endif
         block_barrier();
 #pragma unroll
         for (int d = 0; d + 1 < D; ++d) q[d] = q[d + 1];
         q[D - 1] = fut;
-        bi = bi + 1 == (uint32_t)C::NBUF ? 0 : bi + 1;
+        free_dw = img_dw;
+        img_dw = img_dw + C::BUF_DW == C::NBUF * C::BUF_DW ? 0 : img_dw + C::BUF_DW;
+        ra += nblocks * C::GROUP;
+        p_rec += stride;
     }
     if constexpr (GH) {
         if (it > 0 && w == ((it - 1) & (C::WPB - 1))) {             // the last group's hashes (behind the loop's final barrier)

@@ -242,6 +242,15 @@ CK_DEV void glds16_async_s(uint32_t* lds_dst, const uint8_t* sbase, uint32_t vof
     // 4.32 ms plain, 4.39 nt loads, 4.43 nt stores, 4.98 sc1 stores)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
 }
+// Touches global memory ahead of its use: every lane fetches 4 bytes at sbase + voff by LDS-DMA into a dump area of 256 bytes
+// (nobody reads it).  No VGPR destination, so nothing ever waits for it but the hand-counted vmcnt of the caller's loop (one
+// more vector-memory instruction in its order).  What it is for: the line is in the L2 when the scalar load of the next
+// iteration asks for it.
+CK_DEV void glds4_touch(uint32_t* lds_dump, const void* sbase, uint32_t voff)
+{
+    const uint32_t dst = (uint32_t)(uintptr_t)lds_dump;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(sbase), "s"(dst) : "memory", "m0");
+}
 template <int N>
 CK_DEV void vmem_wait()
 {

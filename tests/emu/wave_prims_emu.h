@@ -130,6 +130,7 @@ CK_DEV void lds_atomic_add(uint32_t* p, uint32_t v) { *p += v; }
 struct ck_u32x4v { uint32_t x, y, z, w; };
 CK_DEV void glds16_async(uint32_t* lds_dst, const uint8_t* gsrc) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), gsrc, 16); }
 CK_DEV void glds16_async_s(uint32_t* lds_dst, const uint8_t* sbase, uint32_t voff) { memcpy((uint8_t*)lds_dst + 16 * lane_id(), sbase + voff, 16); }
+CK_DEV void glds4_touch(uint32_t* lds_dump, const void* sbase, uint32_t voff) { memcpy((uint8_t*)lds_dump + 4 * lane_id(), (const uint8_t*)sbase + voff, 4); }
 CK_DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t acc)
 {
     for (int k = 0; k < 4; ++k) { int d = (int)((a >> (8 * k)) & 0xFF) - (int)((b >> (8 * k)) & 0xFF); acc += (uint32_t)(d < 0 ? -d : d); }
