@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host-buffer leg (end_to_end)")
     ap.add_argument("--no-copy", action="store_true", help="skip the same-box plain-copy yardstick (roofline.copy_ceiling_gbps)")
+    ap.add_argument("--no-cli", action="store_true", help="default run only: skip the `cli` block (the circkit binary on 1 GB of FASTA in /dev/shm)")
     ap.add_argument("--no-others", action="store_true",
                     help="default run (canonicalize, 1 GPU) only: skip the `other_workloads` block -- BASELINE configs[2] and [3] and their "
                          "variants, 5 steps each in the same process AFTER the headline's timed region (never inside it; `value` is untouched)")
@@ -373,6 +374,8 @@ def main():
             if not result["cpu_baseline"]["gpu_output_matches"]:
                 print(json.dumps(result))
                 raise SystemExit("GPU output differs from the CPU oracle on the sample")
+        if world == 1 and args.workload == "canonicalize" and not args.no_cli and not args.n_frac and S == 1 and L == 1000:
+            result["cli"] = cli_block(np, torch, d_bytes, d_out, N, L)
         if world == 1 and args.workload == "canonicalize" and not args.no_others and not args.n_frac and S == 1:
             t_o = time.perf_counter()
             result["other_workloads"] = other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_out, N, L, not args.no_cpu)
@@ -404,6 +407,53 @@ def job_oracle_slice(np, torch, args, N, L, rank, d_bytes, state, keys):
     if not np.array_equal(base_canon, exp):
         return "a record's canonical form is not that of the base record its key names"
     return None
+
+
+def cli_block(np, torch, d_bytes, d_out, N, L):
+    """What a user of the drop-in runs: the `circkit` binary (C++ host: reader -> parser pool -> GPU through the C ABI -> emit ->
+    writer) on a FASTA file of the headline batch's first records -- 1 GB in /dev/shm, headers `>r0000000` --, wall time of the
+    whole process (HIP start-up and exit included) into /dev/null and into a /dev/shm file; the file is compared with the
+    device path's canonical bytes (src/utils.rs:9-72, src/canonicalize.rs:31-44).  Never `value`."""
+    import shutil
+    exe = os.path.join(ROOT, "circkit_amd", "circkit")
+    if not os.path.exists(exe) or not os.path.isdir("/dev/shm"):
+        return {"error": "no circkit binary or no /dev/shm"}
+    R = min(N, 1_000_000)
+    if shutil.disk_usage("/dev/shm").free < 3 * R * (L + 11):
+        return {"error": "not enough room in /dev/shm"}
+    tag = "circkit_bench_%d" % os.getpid()
+    src, dst = "/dev/shm/%s_in.fasta" % tag, "/dev/shm/%s_out.fasta" % tag
+
+    def fasta(rows):
+        out = np.empty((R, L + 11), dtype=np.uint8)
+        out[:, 0] = ord(">"); out[:, 1] = ord("r"); out[:, 9] = 10; out[:, L + 10] = 10
+        idx = np.arange(R)
+        for d in range(7):
+            out[:, 8 - d] = 48 + (idx // 10 ** d) % 10
+        out[:, 10:L + 10] = rows
+        return out
+    try:
+        fasta(d_bytes[:R * L].cpu().numpy().reshape(R, L)).tofile(src)
+        res = {"input": "%d records x %d b, %d bytes of FASTA in /dev/shm (the headline batch's first records)" % (R, L, R * (L + 11)),
+               "threads": "default (the CPUs this process may use)"}
+        for sink, target in (("dev_null", "/dev/null"), ("tmpfs_file", dst)):
+            t0 = time.perf_counter()
+            r = subprocess.run([exe, "canonicalize", src, "-o", target], capture_output=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": "circkit canonicalize failed: %s" % r.stderr.decode(errors="replace")[-300:]}
+            res[sink] = {"wall_s": dt, "records_per_s": R / dt, "gbytes_per_s": R * (L + 11) / dt / 1e9}
+        want = fasta(d_out[:R * L].cpu().numpy().reshape(R, L))
+        got = np.fromfile(dst, dtype=np.uint8)
+        res["output_matches_device_path"] = bool(got.size == want.size and np.array_equal(got, want.reshape(-1)))
+        res["note"] = "wall time of the whole process, one run per sink: HIP start-up (~0.3 s) and exit are inside; at 1 GB they are a third of it"
+        return res
+    finally:
+        for f in (src, dst):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
 
 
 def other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_out, N, L, check, steps=5):

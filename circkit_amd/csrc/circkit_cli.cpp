@@ -30,6 +30,7 @@
 #include <condition_variable>
 #include <deque>
 #include <new>
+#include <memory>
 #include <mutex>
 #include <climits>
 #include <string>
@@ -527,6 +528,11 @@ struct Slot {
     bool first = false;
     ckhost::Batch batch;                        // batch.bytes and canon live in pinned memory: DMA both ways
     ckhost::ByteBuf canon;
+    // a chunk is parsed in sub-ranges by several threads (SubBatch: private buffers), then placed into `batch` as ONE CSR
+    struct SubBatch { ckhost::Batch b; size_t start = 0; uint64_t rec0 = 0, byte0 = 0; };
+    std::vector<std::unique_ptr<SubBatch>> sub;
+    int n_sub = 0;
+    std::atomic<int> parse_left{ 0 }, place_left{ 0 };
     std::vector<uint64_t> hash, first_seen;
     uint64_t base = 0;
     // positioned output (regular output file): byte offset of every record inside the chunk's window of the file
@@ -670,10 +676,11 @@ int main(int argc, char** argv)
     }
     circkit_ctx* ctx = nullptr;
     const auto t_start = std::chrono::steady_clock::now();
-    const int rc = circkit_ctx_create(opt.device, &ctx);
-    const double init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    if (rc != CIRCKIT_OK) die(std::string("no usable MI355X GPU (device ") + std::to_string(opt.device) + "): " +
-                               (ctx ? circkit_last_error(ctx) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
+    double init_s = 0;
+    // HIP start-up (0.25-0.35 s) belongs to the GPU thread: reading and the first parses need no device and run next to it
+    std::mutex ctx_m;
+    std::condition_variable ctx_cv;
+    bool ctx_ready = false;
     const bool uniq = opt.cmd == "uniq";
     const bool want_bytes = !uniq || opt.canonicalize;
     int n_parsers = opt.threads > 0 ? opt.threads : default_threads();   // src/commands.rs:120-123
@@ -699,6 +706,34 @@ int main(int argc, char** argv)
         }
         return 0;
     };
+    // the parsers' job queue (stage 2 below); the reader fills it
+    struct ParseJob { long seq; int k; int phase; };
+    std::deque<ParseJob> pjobs;
+    std::mutex pm;
+    std::condition_variable pcv;
+    long chunks_parsed = 0, chunks_total = -1;        // (under pm; chunks_total: set by the reader at EOF)
+    // first record start at or behind `target` in text[0, len): a '>' at the start of a line; len if there is none
+    auto record_start_from = [](const uint8_t* text, size_t len, size_t target) -> size_t {
+        size_t k = target;
+        while (k < len) {
+            const void* g = memchr(text + k, '>', len - k);
+            if (!g) return len;
+            const size_t gi = (const uint8_t*)g - text;
+            if (gi == 0 || text[gi - 1] == '\n') return gi;
+            k = gi + 1;
+        }
+        return len;
+    };
+    auto dispatch_chunk = [&](long seq) {             // (reader thread, after the slot is READ)
+        Slot& s = P.slot[seq % Pipeline::K];
+        static const size_t sub_bytes = getenv("CIRCKIT_CLI_SUB_KB") && atoi(getenv("CIRCKIT_CLI_SUB_KB")) > 0 ? (size_t)atoi(getenv("CIRCKIT_CLI_SUB_KB")) << 10 : (size_t)2 << 20;
+        int n = (int)(s.len / sub_bytes);
+        n = n < 1 ? 1 : (n > n_parsers ? n_parsers : n);
+        while ((int)s.sub.size() < n) s.sub.emplace_back(new Slot::SubBatch());
+        s.n_sub = n; s.parse_left = n; s.place_left = n;
+        { std::lock_guard<std::mutex> g(pm); for (int k = 0; k < n; ++k) pjobs.push_back(ParseJob{ seq, k, 0 }); }
+        pcv.notify_all();
+    };
     // ---- stage 1: reader.  Cuts every chunk at a record start so the parsers never see a partial record.
     std::thread reader([&] {
         long seq = 0;
@@ -718,6 +753,7 @@ int main(int argc, char** argv)
                 s.text = in.map + pos; s.len = cut; s.first = seq == 0;
                 pos += cut;
                 P.set(seq, READ);
+                dispatch_chunk(seq);
                 ++seq;
             } while (pos < in.map_len);
         } else {
@@ -747,35 +783,88 @@ int main(int argc, char** argv)
                 s.text = s.own.data(); s.len = cut; s.first = seq == 0;
                 if (cut == 0 && eof && carry.empty() && seq > 0) break;
                 P.set(seq, READ);
+                dispatch_chunk(seq);
                 ++seq;
             }
         }
         { std::lock_guard<std::mutex> g(P.m); P.n_chunks = seq; }
         P.cv.notify_all();
+        { std::lock_guard<std::mutex> g(pm); chunks_total = seq; }
+        pcv.notify_all();
         // (Handing the slots' page-locked buffers back from here while the last chunks drain -- unpinning the ring's 768 MB is
         // 0.12 s of the process's exit -- was measured: hipHostFree waits for the device and holds up the copies still queued;
         // the pipeline's tail grew by more than the exit shrank, 0.97-1.03 -> 1.16-1.23 s wall into /dev/null.)
     });
 
-    // ---- stage 2: parsers (FASTA record boundaries + needletail normalize + CSR pack), any order
+    // ---- stage 2: parsers (FASTA record boundaries + needletail normalize + CSR pack).  A chunk is cut into sub-ranges at
+    // record starts and every sub-range is a job of its own (round 3: one thread per 64 MB chunk, 27 ms -- with six chunks in
+    // flight that latency bounded the whole pipeline): phase A parses a sub-range into private buffers, the last A job of a
+    // chunk lays the chunk's CSR out (prefix sums over the sub-ranges' record and byte counts), phase B copies every
+    // sub-range's payload, offsets and spans to their place in the chunk's batch -- one contiguous CSR, as the GPU call wants.
     std::vector<std::thread> parsers;
     for (int t = 0; t < n_parsers; ++t)
         parsers.emplace_back([&] {
             for (;;) {
-                long seq;
-                { std::lock_guard<std::mutex> g(P.m); seq = P.next_parse++; }
-                if (!P.wait(seq, READ)) return;
+                ParseJob j;
+                {
+                    std::unique_lock<std::mutex> g(pm);
+                    pcv.wait(g, [&] { return !pjobs.empty() || (chunks_total >= 0 && chunks_parsed >= chunks_total); });
+                    if (pjobs.empty()) return;
+                    j = pjobs.front(); pjobs.pop_front();
+                }
                 Busy::Scope tb(g_parse);
-                Slot& s = P.slot[seq % Pipeline::K];
-                std::string err;
-                size_t consumed = 0;
-                if (!ckhost::parse_chunk(s.text, s.len, s.first, true, s.batch, &consumed, err)) die(err);
-                P.set(seq, PARSED);
+                Slot& s = P.slot[j.seq % Pipeline::K];
+                Slot::SubBatch& sb = *s.sub[j.k];
+                if (j.phase == 0) {
+                    const size_t t0 = s.len / s.n_sub * j.k, t1 = s.len / s.n_sub * (j.k + 1);
+                    const size_t b0 = j.k == 0 ? 0 : record_start_from(s.text, s.len, t0);
+                    const size_t b1 = j.k + 1 == s.n_sub ? s.len : record_start_from(s.text, s.len, t1);
+                    sb.start = b0;
+                    std::string err;
+                    size_t consumed = 0;
+                    if (b1 > b0 || j.k == 0) {
+                        if (!ckhost::parse_chunk(s.text + b0, b1 - b0, s.first && j.k == 0, true, sb.b, &consumed, err)) die(err);
+                    } else { sb.b.clear(); sb.b.offsets.push_back(0); }
+                    if (--s.parse_left == 0) {
+                        // layout of the chunk's CSR; the payload buffer is page-locked: the device must be there first
+                        uint64_t rec = 0, bytes = 0;
+                        for (int k = 0; k < s.n_sub; ++k) { Slot::SubBatch& q = *s.sub[k]; q.rec0 = rec; q.byte0 = bytes; rec += q.b.n(); bytes += q.b.offsets[q.b.n()]; }
+                        { std::unique_lock<std::mutex> g(ctx_m); ctx_cv.wait(g, [&] { return ctx_ready; }); }
+                        s.batch.text = s.text;
+                        s.batch.head.resize(rec); s.batch.raw.resize(rec); s.batch.offsets.resize(rec + 1);
+                        s.batch.bytes.len = 0;
+                        s.batch.bytes.reserve(bytes + 64);
+                        s.batch.bytes.len = bytes + 64;
+                        s.batch.offsets[rec] = bytes;
+                        memset(s.batch.bytes.data() + bytes, 0, 64);
+                        { std::lock_guard<std::mutex> g(pm); for (int k = 0; k < s.n_sub; ++k) pjobs.push_front(ParseJob{ j.seq, k, 1 }); }
+                        pcv.notify_all();
+                    }
+                } else {
+                    const uint64_t n = sb.b.n();
+                    if (n) memcpy(s.batch.bytes.data() + sb.byte0, sb.b.bytes.data(), (size_t)sb.b.offsets[n]);
+                    for (uint64_t i = 0; i < n; ++i) {
+                        s.batch.offsets[sb.rec0 + i] = sb.byte0 + sb.b.offsets[i];
+                        s.batch.head[sb.rec0 + i] = ckhost::Span{ sb.b.head[i].off + sb.start, sb.b.head[i].len };
+                        s.batch.raw[sb.rec0 + i] = ckhost::Span{ sb.b.raw[i].off + sb.start, sb.b.raw[i].len };
+                    }
+                    if (--s.place_left == 0) {
+                        { std::lock_guard<std::mutex> g(pm); ++chunks_parsed; }
+                        pcv.notify_all();
+                        P.set(j.seq, PARSED);
+                    }
+                }
             }
         });
 
     // ---- stage 3: GPU, in input order (one ctx, one thread): canonical bytes / hashes / first-seen
     std::thread gpu([&] {
+        const int rc = circkit_ctx_create(opt.device, &ctx);
+        init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        if (rc != CIRCKIT_OK) die(std::string("no usable MI355X GPU (device ") + std::to_string(opt.device) + "): " +
+                                   (ctx ? circkit_last_error(ctx) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
+        { std::lock_guard<std::mutex> g(ctx_m); ctx_ready = true; }
+        ctx_cv.notify_all();
         uint64_t base = 0;
         for (long seq = 0; P.wait(seq, PARSED); ++seq) {
             Busy::Scope tb(g_gpu);

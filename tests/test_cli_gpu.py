@@ -229,11 +229,13 @@ def test_record_longer_than_a_pipeline_chunk(tmp_path):
     assert r.stdout == want                                  # all records distinct: uniq -c prints the same file
 
 
-@pytest.mark.parametrize("slots,chunk_mb", [("2", "1"), ("3", "2"), ("32", "1"), ("6", "64")])
-def test_chunk_ring_geometry(tmp_path, slots, chunk_mb):
+@pytest.mark.parametrize("slots,chunk_mb,sub_kb", [("2", "1", None), ("3", "2", "64"), ("32", "1", "1"), ("6", "64", None), ("6", "64", "16"), ("4", "4", "300")])
+def test_chunk_ring_geometry(tmp_path, slots, chunk_mb, sub_kb):
     """CIRCKIT_CLI_SLOTS x CIRCKIT_CLI_CHUNK_MB (the ring of chunks in flight: reader -> parsers -> device -> emit -> the
     writer thread): a 9 MB input with records that straddle chunk ends -- among them one longer than a chunk -- gives the
-    same bytes for every geometry, for canonicalize into a file, uniq into a pipe and uniq --table."""
+    same bytes for every geometry, for canonicalize into a file, uniq into a pipe and uniq --table.  sub_kb (CIRCKIT_CLI_SUB_KB):
+    the size of the sub-ranges a chunk is parsed in by several threads before they are placed into one CSR (round 4) -- down to
+    sub-ranges smaller than a record, where most of them come out empty."""
     import numpy as np
     from oracle import oracle as O
     rng = np.random.default_rng(11)
@@ -248,6 +250,8 @@ def test_chunk_ring_geometry(tmp_path, slots, chunk_mb):
     src = tmp_path / "in.fasta"
     src.write_bytes(data)
     env = dict(os.environ, CIRCKIT_CLI_SLOTS=slots, CIRCKIT_CLI_CHUNK_MB=chunk_mb)
+    if sub_kb:
+        env["CIRCKIT_CLI_SUB_KB"] = sub_kb
     out = tmp_path / "out.fasta"
     r = subprocess.run([BIN, "canonicalize", str(src), "-o", str(out)], capture_output=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
