@@ -20,8 +20,12 @@
 //    LDS words -- no second pass, no mirrored address arithmetic, no cross-lane traffic.
 //  * Full 16-byte stores only (the last window is pulled back to end at n, as in the register routine).
 //  * NM (batches with N, MODE_ALPHA): N packed as G, canon_record_mode2n's rules (a key with an N is below its true value;
-//    the winner stands if its window is N-free, or by the prefix rule) -- but the N are kept as a LIST of record positions
-//    instead of a bitmask: the scans never look at them, the output is written as if they were G / C and patched behind.
+//    the winner stands if its window is N-free, or by the prefix rule).  The N are kept as ONE bit per symbol next to the
+//    strand, in the strand's own coordinates (16 bits per strand word, straight from the packing step, extended periodically
+//    like the strand): the scans never look at them; the winning window, the exact comparison of sharers and the output read
+//    16-symbol windows of it.  The output is patched IN REGISTERS before its 16-byte stores (round 3 kept a list of N
+//    positions instead -- a 50th of the LDS -- and patched single bytes behind the stores: +15 % of HBM traffic from the
+//    partial writes, a vmcnt(0) per record, a list walk per winner, and no fused XXH3 for records with N).
 #pragma once
 #include "canon_core.h"
 #include "canon_fast.h"
@@ -35,18 +39,23 @@ namespace ck {
 CK_DEV uint32_t lean_strand_dw(uint32_t n) { return 1 + (n + 30) / 16 + 2; }
 
 struct LeanGeom { uint32_t a16, n, T, nW; };      // T = a16 + n: LDS symbol index of the record's end; nW = strand words
+// NM: dwords of the N bits -- one 16-bit entry per strand word E[-1] .. E[nW] (bit 15 = the word's first symbol)
+CK_DEV uint32_t lean_mask_dw(uint32_t n) { return ((n + 30) / 16 + 3 + 1) / 2; }
+// the N bits of the 16 symbols at LDS symbol index s (bit 15 = the first); Mk[-1] .. Mk[nW] are valid
+CK_DEV uint32_t lean_mask_window(const uint16_t* Mk, int32_t s)
+{
+    const uint32_t two = ((uint32_t)Mk[s >> 4] << 16) | Mk[(s >> 4) + 1];
+    return (two >> (16 - ((uint32_t)s & 15))) & 0xFFFFu;
+}
 
 // the 16 symbols at LDS symbol index s (first in the top bits); E[-1] .. E[nW] are valid
 CK_DEV uint32_t lean_window(const uint32_t* E, int32_t s) { return funnel(E[s >> 4], E[(s >> 4) + 1], ((uint32_t)s & 15) * 2); }
 
 // Strand from aligned chunks; returns false when a chunk holds a byte outside the alphabet (the first and last chunk also
 // hold the neighbours' bytes: a stranger there sends the record to stage A for nothing, which is harmless).
-// NM: N is packed as G and its record position appended to the wave's N LIST (nl: 16-bit entries, nl_cap of them, the
-// counter *nl_count zeroed by the caller) -- with N at 1 % that is a 50th of a bitmask's LDS, so a record of config 4's
-// 20 kb still fits the slice of a CU that holds six workgroups; what the list cannot hold is stage A's (its mode keeps a bitmask).
-// Nothing of the routine's scans ever looks at the list: it is read at the winning window and behind the output.
+// NM: N is packed as G and the chunk's 16 N bits go to Mk[w], as the packing step yields them.
 template <bool NM>
-CK_DEV bool lean_build(const uint8_t* base, const LeanGeom& g, uint32_t* E, uint16_t* nl, uint32_t nl_cap, uint32_t* nl_count)
+CK_DEV bool lean_build(const uint8_t* base, const LeanGeom& g, uint32_t* E, uint16_t* Mk)
 {
     const uint32_t lane = lane_id();
     uint32_t bad = 0;
@@ -63,20 +72,9 @@ CK_DEV bool lean_build(const uint8_t* base, const LeanGeom& g, uint32_t* E, uint
             const uint32_t w = w0 + 64 * u;
             if (w < g.nW) {
                 uint32_t nm = 0, miss = 0;
-                if constexpr (NM) E[w] = fast_pack_n(v[u], nm, miss);
+                if constexpr (NM) { E[w] = fast_pack_n(v[u], nm, miss); Mk[w] = (uint16_t)nm; }
                 else E[w] = fast_pack(v[u], miss);
                 bad |= miss;
-                if constexpr (NM) {
-                    while (nm) {                                          // (bit 15 = the chunk's first symbol)
-                        const uint32_t i = (uint32_t)clz32(nm) - 16;
-                        nm &= ~(0x8000u >> i);
-                        const uint32_t q = 16 * w + i - g.a16;            // record position; the neighbours' bytes fall outside [0, n)
-                        if (q < g.n) {
-                            const uint32_t k = lds_atomic_inc(nl_count);
-                            if (k < nl_cap) nl[k] = (uint16_t)q;
-                        }
-                    }
-                }
             }
         }
     }
@@ -85,51 +83,55 @@ CK_DEV bool lean_build(const uint8_t* base, const LeanGeom& g, uint32_t* E, uint
 
 // Periodic extension on both sides (see the file comment); a handful of lanes, every value computed from the words as
 // built before any is stored.
-CK_DEV void lean_extend(const LeanGeom& g, uint32_t* E)
+template <bool NM = false>
+CK_DEV void lean_extend(const LeanGeom& g, uint32_t* E, uint16_t* Mk = nullptr)
 {
     const uint32_t lane = lane_id();
     const uint32_t jl = g.nW - 1, rl = g.T - 16 * jl;                    // last word, its symbols that belong to the record (1..16)
-    uint32_t val = 0, dst = 0;
+    uint32_t val = 0, dst = 0, mval = 0;
     bool on = false;
     if (lane == 0) {                // word 0: its first a16 symbols become the record's last a16 (LDS indices n .. T)
         const uint32_t w0 = E[0];
         val = g.a16 ? bfi(~(0xFFFFFFFFu >> (2 * g.a16)), lean_window(E, (int32_t)g.n), w0) : w0;
+        if constexpr (NM) mval = g.a16 ? bfi(0xFFFFu >> g.a16, Mk[0], lean_mask_window(Mk, (int32_t)g.n)) : Mk[0];
         dst = 0; on = true;
     } else if (lane == 1) {         // E[-1]: the 16 symbols in front of LDS index 0 = record positions n - 16 - a16 .., at LDS n - 16
         val = lean_window(E, (int32_t)g.n - 16);
+        if constexpr (NM) mval = lean_mask_window(Mk, (int32_t)g.n - 16);
         dst = ~0u; on = true;
     } else if (lane == 2) {         // last word: behind its rl record symbols the record's head (LDS index a16 ..)
         const uint32_t wl = E[jl];
         val = rl < 16 ? bfi(~(0xFFFFFFFFu >> (2 * rl)), wl, lean_window(E, (int32_t)g.a16) >> (2 * rl)) : wl;
+        if constexpr (NM) mval = rl < 16 ? bfi(0xFFFFu >> rl, lean_mask_window(Mk, (int32_t)g.a16) >> rl, Mk[jl]) : Mk[jl];
         dst = jl; on = true;
     } else if (lane == 3) {         // E[nW]: LDS indices 16 nW .. = the same symbols one period earlier
         val = lean_window(E, (int32_t)(16 * g.nW - g.n));
+        if constexpr (NM) mval = lean_mask_window(Mk, (int32_t)(16 * g.nW - g.n));
         dst = g.nW; on = true;
     }
     wave_sync();
-    if (on) { if (dst == ~0u) E[-1] = val; else E[dst] = val; }
+    if (on) {
+        if (dst == ~0u) { E[-1] = val; if constexpr (NM) Mk[-1] = (uint16_t)mval; }
+        else { E[dst] = val; if constexpr (NM) Mk[dst] = (uint16_t)mval; }
+    }
     wave_sync();
 }
 
-// per-lane running minimum over the lane's words (lane l holds words l, l + 64, ...): key, the word that holds it first, how
-// many of the lane's words hold it; SECOND (the N build's prefix rule): the smallest minimum among the lane's OTHER words.
-// (Two words of one lane with the minimum are mostly ONE position seen twice -- in word 0 or 1 and, as its periodic twin, in
-// the last words, which share a lane when the record is a little longer than a multiple of 1024 symbols; lean_locate then
-// walks the lane's words again.)
-struct LeanBest { uint32_t key = ~0u, word, ties = 0, second = ~0u; };
-template <bool SECOND>
+// per-lane running minimum over the lane's words (lane l holds words l, l + 64, ...): key, the word that holds it first, and
+// `second`, the smallest minimum among the lane's OTHER words -- second == key says that more than one of the lane's words
+// holds the minimum (mostly ONE position seen twice: in word 0 or 1 and, as its periodic twin, in the last words, which share
+// a lane when the record is a little longer than a multiple of 1024 symbols; lean_locate then walks the lane's words again),
+// and the N build's prefix rule needs it anyway.  Five instructions per word and strand (v_max, v_min, v_cmp, v_cndmask,
+// v_min; round 3 counted the ties: six, nine in the N build).
+struct LeanBest { uint32_t key = ~0u, word, second = ~0u; };
 CK_DEV void lean_update(LeanBest& b, uint32_t m, uint32_t w)
 {
-    if constexpr (SECOND) {
-        const uint32_t hi = m > b.key ? m : b.key;
-        b.second = hi < b.second ? hi : b.second;
-    }
-    // (key starts at ~0 and word at the lane's first word: a first minimum of ~0 counts as a tie with the initial state, which
-    // names the right word already)
-    const bool lt = m < b.key;
-    b.ties = lt ? 1u : b.ties + (m == b.key ? 1u : 0u);
-    b.word = lt ? w : b.word;
-    b.key = lt ? m : b.key;
+    const uint32_t hi = m > b.key ? m : b.key;
+    b.second = hi < b.second ? hi : b.second;
+    // (key starts at ~0 and word at the lane's first word: a first minimum of ~0 leaves the initial state, which names the
+    // right word already)
+    b.word = m < b.key ? w : b.word;
+    b.key = m < b.key ? m : b.key;
 }
 
 // the keys that start (forward) / end (reverse) in word j, one per lane & 15: forward key at LDS index 16 j + b, reverse key
@@ -177,15 +179,15 @@ template <bool NM>
 CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint32_t M, const LeanBest& b)
 {
     const uint32_t lane = lane_id();
-    uint64_t hm = ballot(b.ties != 0 && b.key == M);
-    if (ballot(b.ties > 4 && b.key == M) != 0 || popc64(hm) > 8) return -1;
+    uint64_t hm = ballot(lane < g.nW && b.key == M);              // (lanes without a word keep the initial key)
+    if (popc64(hm) > 8) return -1;
     int32_t Q = -1;
     uint32_t rivals = 0;
     while (hm) {
         const uint32_t l = (uint32_t)ffs64(hm);
         hm &= hm - 1;
         // the owner lane's word with the minimum -- or, when two of its words hold it, every word of the lane from that one on
-        const uint32_t j0 = readlane(b.word, l), j1 = readlane(b.ties, l) == 1 ? j0 + 1 : g.nW;
+        const uint32_t j0 = readlane(b.word, l), j1 = readlane(b.second, l) != M ? j0 + 1 : g.nW;
         for (uint32_t j = j0; j < j1; j += 64) {
             const uint32_t key = lean_key_at(E, j, lane & 15, fwd);
             uint64_t pm = ballot(lane < 16 && key == M);
@@ -217,11 +219,10 @@ CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint3
 // Before this, such a record cost stage A a 2-bit attempt, then the 4-bit mode on one wave behind everything else: 0.38 ms
 // of config 4's 2.4 ms step with 1 % N, for 1 % of its bytes.
 constexpr uint32_t LEAN_CAND_MAX = 16, LEAN_CAND_DW = LEAN_CAND_MAX + 2;        // + counter, + the candidate's N mask
-CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom& g, const uint16_t* nl, uint32_t n_n, uint32_t thr, uint32_t* cand)
+CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom& g, const uint16_t* Mk, uint32_t thr, uint32_t* cand)
 {
     const uint32_t lane = lane_id(), n = g.n;
     uint32_t* count = cand + LEAN_CAND_MAX;
-    uint32_t* nmask = cand + LEAN_CAND_MAX + 1;
     if (lane == 0) *count = 0;
     wave_sync();
     // forward windows: LDS indices a16 .. T - 1.  Reverse keys: the loop yields the forward windows at 16 w - b, i.e. indices
@@ -254,21 +255,15 @@ CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom& g, co
     for (uint32_t k = 0; k < c; ++k) {
         const uint32_t v = cand[k], q = v & 0x7FFFFFFFu;
         const bool f = (v >> 31) == 0;
-        // which of the rotation's first 32 symbols are N: symbol i is forward position q + i, or (reverse strand) q + 15 - i
-        if (lane == 0) *nmask = 0;
-        wave_sync();
-        for (uint32_t e = lane; e < n_n; e += 64) {
-            const int32_t d0 = f ? (int32_t)nl[e] - (int32_t)q : (int32_t)q + 15 - (int32_t)nl[e];
-            const int32_t d = d0 < 0 ? d0 + (int32_t)n : (d0 >= (int32_t)n ? d0 - (int32_t)n : d0);
-            if (d < 32) lds_atomic_or(nmask, 1u << d);
-        }
-        wave_sync();
-        const uint32_t nm = *nmask;
-        wave_sync();                                        // (everybody has it before lane 0 clears the word for the next candidate)
+        // which of the rotation's first 32 symbols are N: symbol i is forward position q + i, or (reverse strand) q + 15 - i --
+        // the N bits of the same two windows the symbols come from (bit 15 = the window's first forward position)
         // the symbol itself: two 16-symbol windows (the second one 16 further on the strand that is being read)
         const uint32_t q2 = f ? (q + 16 >= n ? q + 16 - n : q + 16) : (q >= 16 ? q - 16 : q + n - 16);
         uint32_t x0 = lean_window(E, (int32_t)(q + g.a16)), x1 = lean_window(E, (int32_t)(q2 + g.a16));
+        uint32_t m0 = lean_mask_window(Mk, (int32_t)(q + g.a16)), m1 = lean_mask_window(Mk, (int32_t)(q2 + g.a16));
         if (!f) { x0 = rc_word<2>(x0); x1 = rc_word<2>(x1); }
+        else { m0 = bitrev(m0) >> 16; m1 = bitrev(m1) >> 16; }                // bit i = symbol i of the rotation, either way
+        const uint32_t nm = m0 | (m1 << 16);
         const uint32_t sym = ((lane & 16) ? x1 : x0) >> (30 - 2 * (lane & 15)) & 3u;
         const uint32_t rank = lane < 32 ? (((nm >> lane) & 1u) ? 5u : 2u * sym) : 0u;
         if (best == ~0u) { best = v; best_rank = rank; continue; }
@@ -288,6 +283,18 @@ CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom& g, co
 // its cells' products to the accumulators, full blocks are followed by XXH3's scramble, and the last stripe, the merge and
 // the avalanche follow behind the loop.  Per-pair constants live in a 64-dword LDS table (lean_hash_table_init: last-stripe
 // and merge secrets, initial accumulators, scramble secrets); the per-lane stripe secrets stay in registers.
+// N builds: nibble of N bits (bit 3 = the first of four output bytes) -> 'G' ^ 'N' = 0x09 (forward strand, entries 0..15) or
+// 'C' ^ 'N' = 0x0D (reverse strand, entries 16..31) in the bytes the bits name
+constexpr uint32_t LEAN_LUTN_DW = 32;
+CK_DEV void lean_lutn_init(uint32_t* tab, uint32_t tid, uint32_t nthreads)
+{
+    for (uint32_t x = tid; x < 32; x += nthreads) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o |= ((x >> (3 - k)) & 1u) << (8 * k);
+        tab[x] = o * (x < 16 ? 0x09u : 0x0Du);
+    }
+}
 constexpr uint32_t LEAN_HASH_TABLE_DW = 64;          // per pair j (16 dwords): l0 l1 m0 m1 i0 i1 sc0 sc1
 CK_DEV void lean_hash_table_init(uint32_t* tab, uint32_t tid)
 {
@@ -349,7 +356,7 @@ CK_DEV uint64_t lean_hash_finish(LeanHash& h, const uint32_t* tab, u32x4 cell, u
 #endif
 template <bool NM, bool HASH = false>
 CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uint32_t n, uint64_t payload_end, uint32_t* slice,
-                             const uint32_t* lut, const uint32_t* htab = nullptr, uint64_t hk0 = 0, uint64_t hk1 = 0)
+                             const uint32_t* lut, const uint32_t* htab = nullptr, uint64_t hk0 = 0, uint64_t hk1 = 0, const uint32_t* lutn = nullptr)
 {
     const uint32_t lane = lane_id();
     LeanGeom g;
@@ -365,31 +372,23 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         g.a16 = 0; g.T = n; g.nW = (n + 15) >> 4;
     }
     const uint32_t strand_dw = lean_strand_dw(n);
-    if (strand_dw + (NM ? LEAN_CAND_DW : 0) > a.slice_dw || (NM && n > 0xFFFFu)) return 2;
+    if (strand_dw + (NM ? lean_mask_dw(n) + LEAN_CAND_DW : 0) > a.slice_dw) return 2;
     uint32_t* E = slice + 1;
-    uint32_t* nl_count = E + g.nW + 1;                                    // (the strand's spare word)
-    uint16_t* nl = reinterpret_cast<uint16_t*>(slice + strand_dw);
-    // (NM: the slice's last LEAN_CAND_DW dwords are lean_resolve_n's candidate list)
-    const uint32_t nl_cap = NM && a.slice_dw > strand_dw + LEAN_CAND_DW ? 2 * (a.slice_dw - strand_dw - LEAN_CAND_DW) : 0;
-    if constexpr (NM) {
-        if (lane == 0) *nl_count = 0;
-        wave_sync();
-    }
+    // (NM: the N bits behind the strand, lean_resolve_n's candidate list in the slice's last LEAN_CAND_DW dwords)
+    uint16_t* Mk = reinterpret_cast<uint16_t*>(slice + strand_dw) + 1;
     if (inside) {
-        if (!lean_build<NM>(a.bytes + (off - g.a16), g, E, nl, nl_cap, nl_count)) return 1;
+        if (!lean_build<NM>(a.bytes + (off - g.a16), g, E, Mk)) return 1;
     } else {
         if (!build_packed<2>(a.bytes + off, n, E, E)) return 1;         // (its own extension behind the end; lean_extend repeats it)
     }
-    lean_extend(g, E);                                                    // (its wave_sync also publishes the list)
-    const uint32_t n_n = NM ? *nl_count : 0u;
-    if (NM && n_n > nl_cap) return 1;                                     // more N than the list holds: stage A's bitmask mode
+    lean_extend<NM>(g, E, Mk);
     // both strands' minimal keys in one pass over the words
     LeanBest bF, bC;
     bF.word = bC.word = lane;
     for (uint32_t w = lane; w < g.nW; w += 64) {
         const uint32_t cur = E[w], nxt = E[w + 1], prv = E[(int32_t)w - 1];
-        lean_update<NM>(bF, word_min_key<2>(cur, nxt), w);
-        lean_update<NM>(bC, word_min_key<2>(rc_word<2>(cur), rc_word<2>(prv)), w);
+        lean_update(bF, word_min_key<2>(cur, nxt), w);
+        lean_update(bC, word_min_key<2>(rc_word<2>(cur), rc_word<2>(prv)), w);
     }
     uint32_t MF, MC;
     wave_min2_u32(bF.key, bC.key, MF, MC);
@@ -408,20 +407,16 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         if (Q < 0) return 2;
     }
     const uint32_t M = fwd ? MF : MC;
-    const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bties = fwd ? bF.ties : bC.ties;
-    const uint64_t owners = ballot(bties != 0 && bkey == M);
+    const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bsecond = fwd ? bF.second : bC.second;
+    const uint64_t owners = ballot(lane < g.nW && bkey == M);
     // rotation index on the winning strand; the forward window behind reverse position p starts at n - 16 - p
     uint32_t idx = fwd ? (uint32_t)Q : (uint32_t)((int32_t)n - 16 - Q < 0 ? 2 * (int32_t)n - 16 - Q : (int32_t)n - 16 - Q);
     if constexpr (NM) {
         // An N inside the winning window -- the forward positions Q .. Q + 15 on either strand -- is where the packed key
         // differs from the true one: canon_record_mode2n's prefix rule (canon_core.h).  Offset of the first N in the
         // winner's own reading direction: d on the forward strand, 15 - d on the reverse one.
-        uint32_t first = 16;
-        for (uint32_t k = lane; k < n_n; k += 64) {
-            const int32_t d0 = (int32_t)nl[k] - Q, d = d0 < 0 ? d0 + (int32_t)n : d0;
-            if (d < 16) { const uint32_t o = fwd ? (uint32_t)d : 15u - (uint32_t)d; first = o < first ? o : first; }
-        }
-        first = wave_min_u32(first);
+        const uint32_t mw = lean_mask_window(Mk, Q + (int32_t)g.a16);
+        const uint32_t first = mw == 0 ? 16u : (fwd ? (uint32_t)clz32(mw) - 16u : (uint32_t)ffs32(mw));
         if (first < 16) {
             const uint32_t plen = fwd ? first + 1 : first;
             if (plen == 0) return 1;
@@ -431,15 +426,15 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
             // winner itself -- decided without another pass over the strand.
             const uint32_t sh = 32 - 2 * plen, thr = M | (sh ? 0xFFFFFFFFu >> (32 - sh) : 0u);
             const bool mine = ((owners >> lane) & 1) != 0;
-            const uint32_t lowest_other = fwd ? bC.key : bF.key, lowest_w = mine ? (fwd ? bF.second : bC.second) : bkey;
+            const uint32_t lowest_other = fwd ? bC.key : bF.key, lowest_w = mine ? bsecond : bkey;
             bool alone = plen >= CK_LEAN_MIN_PREFIX && ballot(lowest_other <= thr || lowest_w <= thr) == 0;
             for (uint64_t h2 = owners; alone && h2; h2 &= h2 - 1) {
                 const uint32_t l = (uint32_t)ffs64(h2), j = readlane(bword, l);
-                if (readlane(bties, l) != 1 || popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) alone = false;
+                if (readlane(bsecond, l) == M || popc64(ballot(lane < 16 && lean_key_at(E, j, lane & 15, fwd) <= thr)) != 1) alone = false;
             }
             if (!alone) {
                 // other rotations share those symbols: the true minimum is one of the sharers (lean_resolve_n)
-                const uint32_t v = lean_resolve_n(E, g, nl, n_n, thr, slice + a.slice_dw - LEAN_CAND_DW);
+                const uint32_t v = lean_resolve_n(E, g, Mk, thr, slice + a.slice_dw - LEAN_CAND_DW);
                 if (v == ~0u) return 1;
                 fwd = (v >> 31) == 0;
                 Q = (int32_t)(v & 0x7FFFFFFFu);
@@ -447,10 +442,10 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
             }
         }
     }
-    // XXH3 fused (HASH builds): pure records of more than 240 symbols; what is not fused -- the N build's records (their
-    // bytes are patched behind the stores), the short-input classes -- is the xxh3 pass's, from the bytes or, when no bytes
-    // were asked for, from the view
-    const bool fused = HASH && !NM && a.out_hash != nullptr && n > 240;
+    // XXH3 fused (HASH builds): records of more than 240 symbols, with or without N (round 4: the N are patched into the cells
+    // in registers, so the hash sees the bytes that are stored); the short-input classes are the xxh3 pass's, from the bytes
+    // or, when no bytes were asked for, from the view
+    const bool fused = HASH && a.out_hash != nullptr && n > 240;
     if (HASH && !fused && a.out_view && lane == 0) a.out_view[rec] = fwd ? idx : (idx | 0x80000000u);
     if (a.out_bytes || fused) {
         uint8_t* out = a.out_bytes ? a.out_bytes + off : nullptr;
@@ -459,14 +454,24 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         const auto cell_at = [&](uint32_t o, bool f) {
             uint32_t p = idx + o;
             p = p >= n ? p - n : p;
-            if (f) return fast_decode(lut, lean_window(E, (int32_t)(p + g.a16)));
-            const uint32_t s = (p + 16 <= n ? n - 16 - p : 2 * n - 16 - p) + g.a16;       // LDS index of the forward window behind them
-            return fast_decode(lut, rc_word<2>(lean_window(E, (int32_t)s)));
+            // LDS index of the forward window behind the 16 bytes (reverse strand: read backwards)
+            const uint32_t s = f ? p + g.a16 : (p + 16 <= n ? n - 16 - p : 2 * n - 16 - p) + g.a16;
+            u32x4 c = fast_decode(lut, f ? lean_window(E, (int32_t)s) : rc_word<2>(lean_window(E, (int32_t)s)));
+            if constexpr (NM) {
+                // the decoded G (forward) / C (reverse) of every N becomes N: four bits of the window's mask -> the XOR constant
+                // in the bytes they name, by a 16-entry table per strand (lean_lutn_init); output byte j is the window's symbol
+                // j (forward) or 15 - j (reverse).  No branch around it: at 1 % N some lane of a row always has one.
+                uint32_t m = lean_mask_window(Mk, (int32_t)s);
+                if (!f) m = bitrev(m) >> 16;
+                const uint32_t* tab = lutn + (f ? 0 : 16);
+                c.x ^= tab[m >> 12]; c.y ^= tab[(m >> 8) & 15]; c.z ^= tab[(m >> 4) & 15]; c.w ^= tab[m & 15];
+            }
+            return c;
         };
         if (!fused) {
             if (fwd) { for (uint32_t w = lane; 16 * w < n; w += 64) { const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16; store16(out + o, cell_at(o, true)); } }
             else { for (uint32_t w = lane; 16 * w < n; w += 64) { const uint32_t o = 16 * w + 16 <= n ? 16 * w : n - 16; store16(out + o, cell_at(o, false)); } }
-        } else if constexpr (HASH && !NM) {
+        } else if constexpr (HASH) {
             LeanHash h;
             h.a0 = lean_hash_const(htab, 4); h.a1 = lean_hash_const(htab, 5);
             h.k0 = hk0; h.k1 = hk1;                                                // (the lane's stripe secrets: FastHashConst::k0 / k1)
@@ -484,18 +489,6 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
             const u32x4 last = fwd ? cell_at(n - 64 + 16 * (lane & 3), true) : cell_at(n - 64 + 16 * (lane & 3), false);
             const uint64_t hv = lean_hash_finish(h, htab, last, n);
             if (lane == 0) { a.out_hash[rec] = hv; a.hashed[rec] = 1; }
-        }
-        if constexpr (NM) {
-            if (n_n && out) {
-                // the decoded G (forward) / C (reverse) of every listed position becomes N: single-byte stores BEHIND the
-                // 16-byte stores that cover the same bytes (vmcnt(0): those have been performed)
-                wave_sync();
-                vmem_wait<0>();
-                for (uint32_t k = lane; k < n_n; k += 64) {
-                    const int32_t q = (int32_t)nl[k], p = fwd ? q : (int32_t)n - 1 - q, o0 = p - (int32_t)idx, o = o0 < 0 ? o0 + (int32_t)n : o0;
-                    out[o] = 'N';
-                }
-            }
         }
     }
     return 0;
@@ -579,7 +572,8 @@ CK_DEV bool mixed_short_n(const CanonArgs& a, const uint32_t* lut, RescueState<H
 // One wave's share of segment `sgm` of a mode-3 batch (seg_records), every wpb-th record from wib on.
 template <bool NM, bool HASH = false>
 CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint32_t* lut, RescueState<HASH, false>& st,
-                                uint32_t* blk_count, uint32_t sgm, uint32_t wib, uint32_t wpb, uint64_t payload_end, const uint32_t* htab = nullptr)
+                                uint32_t* blk_count, uint32_t sgm, uint32_t wib, uint32_t wpb, uint64_t payload_end, const uint32_t* htab = nullptr,
+                                const uint32_t* lutn = nullptr)
 {
     uint64_t first;
     uint32_t count;
@@ -598,7 +592,7 @@ CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint3
         // longer records -- and (pure build) the few short ones the register routine leaves (a tied minimal key, a minimal key
         // both strands own): the lean LDS routine
         if (len >= FAST_MIN_N && len < (1ull << 31) && !not_acgt && !tried) {
-            const int r = canon_lean_record<NM, HASH>(a, rec, off, (uint32_t)len, payload_end, slice, lut, htab, st.hc.k0, st.hc.k1);
+            const int r = canon_lean_record<NM, HASH>(a, rec, off, (uint32_t)len, payload_end, slice, lut, htab, st.hc.k0, st.hc.k1, lutn);
             wave_sync();                                    // every lane is done with the slice before the next record's build
             if (r == 0) continue;
             not_acgt = NM || r == 1;

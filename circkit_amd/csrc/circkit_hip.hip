@@ -393,8 +393,10 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* blk_count = lds + 4 * a.slice_dw;
     uint32_t* lut = blk_count + 4;
-    uint32_t* htab = lut + ck::FAST_LUT_DW;                // (HASH builds: the XXH3 per-pair constants, in the place of the tiers' N patch table + 48 dwords)
+    uint32_t* lutn = lut + ck::FAST_LUT_DW;                // N builds: the 'G' / 'C' -> 'N' patch tables (the output is patched in registers)
+    uint32_t* htab = lutn + ck::LEAN_LUTN_DW;              // (HASH builds: the XXH3 per-pair constants)
     ck::fast_lut_init(lut, threadIdx.x, 256);
+    if (NM) ck::lean_lutn_init(lutn, threadIdx.x, 256);
     if (HASH) ck::lean_hash_table_init(htab, threadIdx.x);
     ck::RescueState<HASH, false> st;
     if (HASH) {                                          // (only the lane's stripe secrets stay in registers: lean_hash_refill)
@@ -408,7 +410,7 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
     for (uint32_t sgm = blockIdx.x; sgm < a.in_nseg; sgm += gridDim.x) {
         if (threadIdx.x == 0) { blk_count[0] = 0; }
         __syncthreads();
-        ck::canon_mixed_segment<NM, HASH>(a, slice, lut, st, blk_count, sgm, wib, 4, payload_end, htab);
+        ck::canon_mixed_segment<NM, HASH>(a, slice, lut, st, blk_count, sgm, wib, 4, payload_end, htab, lutn);
         __syncthreads();
         if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
     }
@@ -425,13 +427,13 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
 #endif
 }
 #ifndef CK_MIXED_NM_VGPR
-#define CK_MIXED_NM_VGPR 36
+#define CK_MIXED_NM_VGPR 48       // the N builds: five workgroups per CU by LDS (strand + N bits) = five waves per SIMD: 96 registers each
 #endif
 #ifndef CK_MIXED_H_VGPR
 #define CK_MIXED_H_VGPR 40       // the builds with the fused XXH3: 80 registers, six waves per SIMD
 #endif
 #ifndef CK_MIXED_N_SLICE
-#define CK_MIXED_N_SLICE 1596     // dwords per wave of canon_mixed_n_kernel: six workgroups per CU by LDS as by SGPRs (measured: 1368 dwords 2.38 ms, 1596 2.33 -- the N list of a 20 kb record needs the room)
+#define CK_MIXED_N_SLICE 1904     // dwords per wave of the N builds: strand + N bits + candidates of a 20 kb record (1253 + 628 + 18); five workgroups per CU by LDS
 #endif
 #ifdef CK_MIXED_WAVES
 #define CK_MIXED_ATTR(VGPR) __launch_bounds__(256, CK_MIXED_WAVES)
@@ -447,7 +449,7 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
 CK_MIXED_KERNEL(canon_mixed_kernel, false, false, 36)
 CK_MIXED_KERNEL(canon_mixed_n_kernel, true, false, CK_MIXED_NM_VGPR)
 CK_MIXED_KERNEL(canon_mixed_h_kernel, false, true, CK_MIXED_H_VGPR)          // + XXH3 (uniq on batches of mixed lengths)
-CK_MIXED_KERNEL(canon_mixed_nh_kernel, true, true, CK_MIXED_H_VGPR)
+CK_MIXED_KERNEL(canon_mixed_nh_kernel, true, true, CK_MIXED_NM_VGPR)
 #undef CK_MIXED_KERNEL
 
 // GH: the fused XXH3 is finished per 16-record group by one wave (canon_fast.h group_hash_*): 18.2 KiB more LDS, which
@@ -1197,10 +1199,10 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             const unsigned full = nseg;
 #endif
             const unsigned grid = expected ? full : walking;
-            // the N build keeps a list of the record's N positions (and lean_resolve_n's candidates) behind the strand: a bigger
-            // slice (six workgroups = 24 waves per CU), so that a 20 kb record of config 4 has room for the ~200 N it holds at 1 %
+            // the N build keeps one N bit per symbol (and lean_resolve_n's candidates) behind the strand: half as much again, so
+            // that a 20 kb record of config 4 fits a slice (n / 16 + n / 32 + 24 dwords) -- five workgroups = 20 waves per CU
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
-            const size_t shmem = (4 * a.slice_dw + 4 + ck::FAST_LUT_DW + (d_hash ? ck::LEAN_HASH_TABLE_DW : 0)) * 4;
+            const size_t shmem = (4 * a.slice_dw + 4 + ck::FAST_LUT_DW + ck::LEAN_LUTN_DW + (d_hash ? ck::LEAN_HASH_TABLE_DW : 0)) * 4;
             if (d_hash) {
                 if (nm) hipLaunchKernelGGL(canon_mixed_nh_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);
                 else hipLaunchKernelGGL(canon_mixed_h_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1);

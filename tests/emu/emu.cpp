@@ -140,7 +140,7 @@ void run_wave(void (*body)(void*), void* arg) { run_block(body, arg, 1); }
 #include "../../circkit_amd/csrc/xxh3_core.h"
 
 namespace {
-struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false, solo = true; const uint32_t* htab = nullptr; };
+struct Launch { ck::CanonArgs a; uint32_t* lds; const uint32_t* lut; const uint32_t* lutn = nullptr; const uint32_t* lean_lutn = nullptr; uint32_t* blk_count; uint32_t block, nblocks, wib; bool all_records = false, alpha = false, solo = true; const uint32_t* htab = nullptr; };
 void mixed_body(void* p)         // one fiber of a 4-wave workgroup of canon_mixed[_n][_h]_kernel (NM = the batch's MODE_ALPHA, HASH = out_hash given)
 {
     Launch* L = (Launch*)p;
@@ -151,11 +151,11 @@ void mixed_body(void* p)         // one fiber of a 4-wave workgroup of canon_mix
         ck::RescueState<true, false> st;
         st.hc.k0 = ck::xsec64(8 * (ck::lane_id() >> 2) + 16 * (ck::lane_id() & 3));
         st.hc.k1 = ck::xsec64(8 * (ck::lane_id() >> 2) + 16 * (ck::lane_id() & 3) + 8);
-        if (L->alpha) ck::canon_mixed_segment<true, true>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end, L->htab);
-        else ck::canon_mixed_segment<false, true>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end, L->htab);
+        if (L->alpha) ck::canon_mixed_segment<true, true>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end, L->htab, L->lean_lutn);
+        else ck::canon_mixed_segment<false, true>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end, L->htab, L->lean_lutn);
     } else {
         ck::RescueState<false, false> st;
-        if (L->alpha) ck::canon_mixed_segment<true, false>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
+        if (L->alpha) ck::canon_mixed_segment<true, false>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end, nullptr, L->lean_lutn);
         else ck::canon_mixed_segment<false, false>(L->a, slice, L->lut, st, L->blk_count, L->block, wib, 4, payload_end);
     }
 }
@@ -273,6 +273,9 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     uint32_t htab[ck::LEAN_HASH_TABLE_DW];
     for (uint32_t tid = 0; tid < 4; ++tid) ck::lean_hash_table_init(htab, tid);
     L.htab = htab;
+    uint32_t lean_lutn[ck::LEAN_LUTN_DW];
+    ck::lean_lutn_init(lean_lutn, 0, 1);
+    L.lean_lutn = lean_lutn;
     for (uint32_t b = 0; b < G; ++b) {
         uint32_t blk = 0;
         L.block = b; L.blk_count = &blk;
