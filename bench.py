@@ -130,6 +130,13 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # CIRCKIT_BENCH_SHARE_GPU=1 + CIRCKIT_BENCH_BACKEND=gloo: a REHEARSAL of the multi-rank path on a one-GPU box -- every rank
+    # on device 0, the collectives over gloo (which moves device tensors through the host; all_gather and all_reduce only, so
+    # `--exchange allgather`).  RCCL refuses two ranks on one device; nothing measured this way is a result.
+    share_gpu = os.environ.get("CIRCKIT_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("CIRCKIT_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or force_dist
@@ -142,7 +149,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
             dist.barrier()
             torch.cuda.synchronize()
         finally:

@@ -235,6 +235,22 @@ def test_bench_uniq_runs_the_exchange_and_counts_globally():
     assert line["cpu_baseline"]["gpu_output_matches"] is True
 
 
+def test_bench_two_ranks_rehearsal_checks_first_seen_across_ranks():
+    """bench.py --workload uniq at world 2 on this one GPU (both ranks on device 0, collectives over gloo: a rehearsal, RCCL
+    refuses two ranks per device): every rank plants duplicates of BOTH ranks' base records, the all-gather exchange resolves
+    first-seen across the ranks inside the timed step, and bench.py's own job-wide check passes -- every record of every shard
+    against the planting decisions, an oracle slice per rank, records owned by the other rank present (VERDICT r03 #1)."""
+    import json
+    out = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+                os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "uniq", "--exchange", "allgather", "--records", "200000",
+                "--steps", "2", "--warmup", "1"], env={"CIRCKIT_BENCH_SHARE_GPU": "1", "CIRCKIT_BENCH_BACKEND": "gloo"})
+    line = json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["unique_records"] == 200000
+    chk = line["uniq_job_check"]
+    assert chk["first_seen_mismatches_job"] == 0 and chk["records_owned_by_another_rank_job"] > 50000
+    assert chk["oracle_slice"]
+
+
 @pytest.mark.parametrize("workload", [["--workload", "uniq"], ["--workload", "mixed", "--with-hash"]])
 def test_bench_hash_only_lines(workload):
     """bench.py --hash-only (`circkit uniq` without --canonicalize: no canonical bytes are written, SURVEY 8d's L + 16 bytes per

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
-B="python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-copy $*"
+B="python $R/bench.py --steps 2 --warmup 1 --no-cpu --no-e2e --no-copy --no-cli --no-others $*"
 cd /tmp
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/$TAG/p1 -- $B > $R/gpurun_out/$TAG.p1.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA --output-format csv -d $R/gpurun_out/$TAG/p2 -- $B > $R/gpurun_out/$TAG.p2.log 2>&1 &&
