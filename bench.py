@@ -357,7 +357,11 @@ def main():
             roofline["table_access_bytes"] = table_bytes
         if not args.no_copy:
             roofline.update(copy_ceiling(torch, ctx, stream, d_bytes, d_out, total, achieved))
-            step()                                      # d_out holds the canonical records again (the checks below read it)
+            # d_out holds the canonical records again (the checks below read it) -- the batch call alone: a whole step() would
+            # enter the exchange's collectives on this rank only
+            with torch.cuda.stream(lanes[0]["stream"]):
+                lanes[0]["ctx"].canonicalize_batch_device(d_bytes, d_off, N, out_bytes=None if (args.hash_only and lanes[0]["hash"] is not None) else lanes[0]["out"],
+                                                          out_xxh3=lanes[0]["hash"])
             torch.cuda.synchronize()
         result = {
             "metric": metric, "value": seq_per_s, "unit": "sequences/s",
