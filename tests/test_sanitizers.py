@@ -38,6 +38,16 @@ def texts():
     cases.append(open(os.path.join(GOLDEN, "nim_cated", "realistic_input.fasta"), "rb").read())
     cases += [b"", b">a", b">a\n", b">a\nACGT", b">a\nACGT\n", b">a b c\nAC\nGT\n>b\n\n>c\nA\n", b"\n\n>a\nAC\n",
               b">a\r\nAC\r\nGT\r\n>b\r\nTT\r\n", b">a\nAC>GT\n>b\nA\n", b">\nACGT\n", b">", b"\n", b">\n>", b">a\n>", b"\r\n\r\n"]
+    # long runs of ACGTN (the packer's sixteen-bytes-at-a-time path) with one stranger at every offset of the first blocks, line
+    # breaks at every width around the block size, and tails of every length behind the last full block
+    rng = random.Random(6)
+    pure = lambda n: bytes(rng.choice(b"ACGTN") for _ in range(n))
+    for off in range(0, 35):
+        for odd in (b"a", b"u", b"\n", b" ", b"-", b"R", b"\r\n"):
+            cases.append(b">x\n" + pure(off) + odd + pure(70 - off) + b"\n>y z\n" + pure(off + 16))
+    for w in (15, 16, 17, 31, 32, 33, 60):
+        seq = pure(200)
+        cases.append(b">w\n" + b"\n".join(seq[i:i + w] for i in range(0, len(seq), w)) + b"\n")
     rng = random.Random(5)
     for _ in range(200):
         recs = []
