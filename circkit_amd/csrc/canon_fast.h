@@ -264,7 +264,11 @@ CK_DEV void fast_shape(FastShape& sh, uint32_t n)
 // (C < G < N), so the winner stands if the symbols that decided -- 8 at level 1, 16 at level 2 -- hold no N; else false,
 // and the caller's 4-bit routine has the record.  `bad` = lanes with a byte outside ACGTN.  (canon_core.h
 // canon_record_mode2n is the same idea in the LDS tiers.)
-template <bool HASH, bool AUX, bool GH = false, bool K16 = false, bool NM = false>
+// TIGHT: the build is at its register limit (the ALPHA and ROWS = 2 streaming builds: 64 registers at 16 waves per workgroup):
+// the scans of the lanes past the record stay behind exec masks -- straight-line, the scheduler interleaves the two strands'
+// scans and keeps ~15 more registers live, which those builds pay for in scratch spills (round 4, measured by PMC: +2 vector
+// stores and +1 load per record in the ALPHA build).
+template <bool HASH, bool AUX, bool GH = false, bool K16 = false, bool NM = false, bool TIGHT = false>
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
                        uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr, uint32_t Nm = 0, uint32_t* view_out = nullptr)
 {
@@ -308,7 +312,9 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         // every lane scans (a VALU instruction costs the same with any exec mask); the lanes past the record are ORed out of
         // the minimum instead of being branched around: `valid ? scan : 0xFFFF` compiled to two exec-mask regions
         // (s_and_saveexec / s_cbranch_execz / s_or: 6 scalar instructions + 2 branches per record)
-        uint32_t mF = word_min_key16(F, Fn) | sh.inv, mC = word_min_key16(C, Cn) | sh.inv;
+        uint32_t mF, mC;
+        if constexpr (TIGHT) { mF = valid ? word_min_key16(F, Fn) : 0xFFFFu; mC = valid ? word_min_key16(C, Cn) : 0xFFFFu; }
+        else { mF = word_min_key16(F, Fn) | sh.inv; mC = word_min_key16(C, Cn) | sh.inv; }
         uint32_t MF, MC;
         wave_min2_u32(mF, mC, MF, MC);
         fwd = fwd_only || MF < MC;

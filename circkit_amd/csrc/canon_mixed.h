@@ -219,7 +219,9 @@ CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint3
 // Before this, such a record cost stage A a 2-bit attempt, then the 4-bit mode on one wave behind everything else: 0.38 ms
 // of config 4's 2.4 ms step with 1 % N, for 1 % of its bytes.
 constexpr uint32_t LEAN_CAND_MAX = 16, LEAN_CAND_DW = LEAN_CAND_MAX + 2;        // + counter, + the candidate's N mask
-CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom& g, const uint16_t* Mk, uint32_t thr, uint32_t* cand)
+// (g BY VALUE: a reference parameter of a non-inlined function makes the caller keep the struct in scratch memory -- one 1 KiB
+// scratch store per record of the N build, +15 % of its write traffic by PMC, for a call one record in fifty makes)
+CK_DEV_NOINLINE uint32_t lean_resolve_n(const uint32_t* E, const LeanGeom g, const uint16_t* Mk, uint32_t thr, uint32_t* cand)
 {
     const uint32_t lane = lane_id(), n = g.n;
     uint32_t* count = cand + LEAN_CAND_MAX;

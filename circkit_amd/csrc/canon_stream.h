@@ -275,15 +275,15 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                     const uint64_t with_n = ballot(nm != 0) & chunks;
                     if (bad == 0) {
                         const uint32_t Fw = lshr64(Pn, wave_shl1(Pn), 32 - 2 * a16);
-                        if (with_n == 0) done = fast_canon<false, false, false, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr);
-                        else done = fast_canon<false, false, false, true, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr, lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
+                        if (with_n == 0) done = fast_canon<false, false, false, true, false, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr);
+                        else done = fast_canon<false, false, false, true, true, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr, lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
                     }
                     bad |= with_n;                  // (what the 4-bit routine is for)
                 } else {
                     uint32_t miss;
                     const uint32_t P = fast_pack(v, miss);
                     bad = ballot(miss != 0) & chunks;
-                    if (!ALPHA || bad == 0) done = fast_canon<HASH, AUX, GH, true>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
+                    if (!ALPHA || bad == 0) done = fast_canon<HASH, AUX, GH, true, false, ALPHA || C::ROWS == 2>(a, lut, hc, shape, rec, off, n, lshr64(P, wave_shl1(P), 32 - 2 * a16), bad, slot);
                 }
                 if (ALPHA && bad != 0 && !done) {
                     // {-,A,C,G,N,T} at 4 bits per symbol: 64 bits per lane, the record's offset in its first chunk
