@@ -535,7 +535,12 @@ def other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_
             ms, N, (2 * total + 16 * N) if out is not None else (total + 16 * N), ok, unique_records=kept,
             check="first %d records: XXH3 + first-seen%s vs the oracle; kept == N/2" % (S, " + canonical bytes" if out is not None else ""))
     del d_hash
-    # ---- configs[3]: 1M records, lengths log-uniform on [200, 20000]; then with 1 % N; the plain one also with the XXH3
+    # ---- configs[3]: 1M records, lengths log-uniform on [200, 20000]; then with 1 % N; the plain one also with the XXH3.
+    # A context of its own, as a job on such a batch would have: the first one's hash table has grown to the 10M-key batch
+    # (grow-only) and a 1M-key batch would pay for clearing and probing all of it.
+    ctx_uniq, ctx = ctx, circkit_amd.Context(dev.index if dev.index is not None else 0)
+    ctx.set_stream(stream.cuda_stream)
+    table = U.DeviceTable(ctx)
     M = 1_000_000
     offs = W.log_uniform_offsets(M, 45, 200, 20000)
     mtotal = int(offs[-1])
@@ -569,6 +574,9 @@ def other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_
     ms = timed(lambda: ctx.canonicalize_batch_device(m_in, m_off, M, out_bytes=m_out))
     entry("mixed_n1pct", "canonicalize, " + wl + ", 1 % of the bases replaced by N", ms, M, 2 * mtotal + 8 * M, mixed_check(False),
           check="first %d records: canonical bytes vs the oracle" % SM)
+    torch.cuda.synchronize()
+    ctx.close()
+    ctx = ctx_uniq
     res["note"] = ("same process and box as the headline, after its timed region and checks; one HIP stream; each entry = 2 warm-up + %d timed "
                    "steps of the whole kernel chain of that workload (HIP events on the launch stream); frac = algorithmic_bytes / time / 8 TB/s" % steps)
     return res
