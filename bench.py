@@ -394,8 +394,10 @@ def main():
             t_o = time.perf_counter()
             result["other_workloads"] = other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_out, N, L, not args.no_cpu)
             result["other_workloads"]["wall_s"] = time.perf_counter() - t_o
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if use_dist:
+        # every rank leaves together: rank 0's epilogue (the copy yardstick, the line) is still running when the others get here
+        dist.barrier()
         dist.destroy_process_group()
     for ln in lanes:
         ln["ctx"].close()
