@@ -712,18 +712,6 @@ int main(int argc, char** argv)
     std::mutex pm;
     std::condition_variable pcv;
     long chunks_parsed = 0, chunks_total = -1;        // (under pm; chunks_total: set by the reader at EOF)
-    // first record start at or behind `target` in text[0, len): a '>' at the start of a line; len if there is none
-    auto record_start_from = [](const uint8_t* text, size_t len, size_t target) -> size_t {
-        size_t k = target;
-        while (k < len) {
-            const void* g = memchr(text + k, '>', len - k);
-            if (!g) return len;
-            const size_t gi = (const uint8_t*)g - text;
-            if (gi == 0 || text[gi - 1] == '\n') return gi;
-            k = gi + 1;
-        }
-        return len;
-    };
     auto dispatch_chunk = [&](long seq) {             // (reader thread, after the slot is READ)
         Slot& s = P.slot[seq % Pipeline::K];
         static const size_t sub_bytes = getenv("CIRCKIT_CLI_SUB_KB") && atoi(getenv("CIRCKIT_CLI_SUB_KB")) > 0 ? (size_t)atoi(getenv("CIRCKIT_CLI_SUB_KB")) << 10 : (size_t)2 << 20;
@@ -816,15 +804,8 @@ int main(int argc, char** argv)
                 Slot& s = P.slot[j.seq % Pipeline::K];
                 Slot::SubBatch& sb = *s.sub[j.k];
                 if (j.phase == 0) {
-                    const size_t t0 = s.len / s.n_sub * j.k, t1 = s.len / s.n_sub * (j.k + 1);
-                    const size_t b0 = j.k == 0 ? 0 : record_start_from(s.text, s.len, t0);
-                    const size_t b1 = j.k + 1 == s.n_sub ? s.len : record_start_from(s.text, s.len, t1);
-                    sb.start = b0;
                     std::string err;
-                    size_t consumed = 0;
-                    if (b1 > b0 || j.k == 0) {
-                        if (!ckhost::parse_chunk(s.text + b0, b1 - b0, s.first && j.k == 0, true, sb.b, &consumed, err)) die(err);
-                    } else { sb.b.clear(); sb.b.offsets.push_back(0); }
+                    if (!ckhost::parse_sub_range(s.text, s.len, s.first, s.n_sub, j.k, sb.b, &sb.start, err)) die(err);
                     if (--s.parse_left == 0) {
                         // layout of the chunk's CSR; the payload buffer is page-locked: the device must be there first
                         uint64_t rec = 0, bytes = 0;
@@ -841,13 +822,7 @@ int main(int argc, char** argv)
                         pcv.notify_all();
                     }
                 } else {
-                    const uint64_t n = sb.b.n();
-                    if (n) memcpy(s.batch.bytes.data() + sb.byte0, sb.b.bytes.data(), (size_t)sb.b.offsets[n]);
-                    for (uint64_t i = 0; i < n; ++i) {
-                        s.batch.offsets[sb.rec0 + i] = sb.byte0 + sb.b.offsets[i];
-                        s.batch.head[sb.rec0 + i] = ckhost::Span{ sb.b.head[i].off + sb.start, sb.b.head[i].len };
-                        s.batch.raw[sb.rec0 + i] = ckhost::Span{ sb.b.raw[i].off + sb.start, sb.b.raw[i].len };
-                    }
+                    ckhost::place_sub_batch(sb.b, sb.start, sb.rec0, sb.byte0, s.batch);
                     if (--s.place_left == 0) {
                         { std::lock_guard<std::mutex> g(pm); ++chunks_parsed; }
                         pcv.notify_all();

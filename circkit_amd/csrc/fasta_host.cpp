@@ -143,6 +143,52 @@ bool parse_chunk(const uint8_t* text, size_t n, bool first_chunk, bool final_chu
     return true;
 }
 
+size_t record_start_from(const uint8_t* text, size_t len, size_t target)
+{
+    size_t k = target;
+    while (k < len) {
+        const void* g = memchr(text + k, '>', len - k);
+        if (!g) return len;
+        const size_t gi = (const uint8_t*)g - text;
+        if (gi == 0 || text[gi - 1] == '\n') return gi;
+        k = gi + 1;
+    }
+    return len;
+}
+
+void sub_range_bounds(const uint8_t* text, size_t len, int n_sub, int k, size_t* b0, size_t* b1)
+{
+    const size_t t0 = len / (size_t)n_sub * (size_t)k, t1 = len / (size_t)n_sub * (size_t)(k + 1);
+    *b0 = k == 0 ? 0 : record_start_from(text, len, t0);
+    *b1 = k + 1 == n_sub ? len : record_start_from(text, len, t1);
+}
+
+bool parse_sub_range(const uint8_t* text, size_t len, bool first_chunk, int n_sub, int k, Batch& sub, size_t* start, std::string& err)
+{
+    size_t b0, b1;
+    sub_range_bounds(text, len, n_sub, k, &b0, &b1);
+    *start = b0;
+    if (b1 > b0 || k == 0) {
+        size_t consumed = 0;
+        return parse_chunk(text + b0, b1 - b0, first_chunk && k == 0, true, sub, &consumed, err);
+    }
+    sub.clear();                    // an empty sub-range (a record longer than the sub-range swallowed it)
+    sub.text = text + b0;
+    sub.offsets.push_back(0);
+    return true;
+}
+
+void place_sub_batch(const Batch& sub, size_t start, uint64_t rec0, uint64_t byte0, Batch& whole)
+{
+    const uint64_t n = sub.n();
+    if (n) memcpy(whole.bytes.data() + byte0, sub.bytes.data(), (size_t)sub.offsets[n]);
+    for (uint64_t i = 0; i < n; ++i) {
+        whole.offsets[rec0 + i] = byte0 + sub.offsets[i];
+        whole.head[rec0 + i] = Span{ sub.head[i].off + start, sub.head[i].len };
+        whole.raw[rec0 + i] = Span{ sub.raw[i].off + start, sub.raw[i].len };
+    }
+}
+
 void csv_field(std::string& out, const uint8_t* p, size_t n, char delim)
 {
     bool quote = n == 0;

@@ -51,6 +51,21 @@ const uint8_t* normalize_lut();
 bool parse_chunk(const uint8_t* text, size_t n, bool first_chunk, bool final_chunk, Batch& out, size_t* consumed,
                  std::string& err);
 
+// ---- a chunk parsed by several threads (the CLI's parser pool, round 4) ---------------------------------------------------
+// The chunk text[0, len) -- cut at a record start by the reader, so it holds whole records only -- is split into n_sub
+// sub-ranges at record starts; every sub-range is parsed on its own into a private Batch (phase A, any thread), the chunk's
+// CSR is laid out by prefix sums over the sub-ranges' record and byte counts, and every sub-range is copied to its place in
+// ONE contiguous CSR (phase B, any thread): the GPU call wants one payload and one offsets array.
+// First record start (a '>' at the start of a line) at or behind `target`; len if there is none.
+size_t record_start_from(const uint8_t* text, size_t len, size_t target);
+// [*b0, *b1) of sub-range k of n_sub: record starts next to the k-th and (k+1)-th n_sub-th of the text
+void sub_range_bounds(const uint8_t* text, size_t len, int n_sub, int k, size_t* b0, size_t* b1);
+// phase A: parses sub-range k into `sub` (spans relative to text + *start)
+bool parse_sub_range(const uint8_t* text, size_t len, bool first_chunk, int n_sub, int k, Batch& sub, size_t* start, std::string& err);
+// phase B: `sub` (parsed from text + start) becomes records [rec0, rec0 + sub.n()) and payload bytes [byte0, ...) of `whole`,
+// whose head / raw / offsets are sized for all records and whose payload buffer holds all bytes already
+void place_sub_batch(const Batch& sub, size_t start, uint64_t rec0, uint64_t byte0, Batch& whole);
+
 // seq_io Record::id(): header up to the first space.
 inline Span record_id(const uint8_t* text, Span head)
 {

@@ -2,6 +2,8 @@
   * the C++ host packer (circkit_amd/csrc/fasta_host.cpp, the code behind circkit_fasta_parse and the CLI's parser threads)
     is built with g++ -fsanitize=address,undefined and fed the texts of tests/test_fasta_host.py -- fixtures, edge cases,
     200 random texts whole and cut in two -- each in a heap block of exactly its size; results are compared with the oracle;
+    every whole text is ALSO parsed the way the CLI's parser pool does it since round 4 -- in 1, 2, 3, 5 and 16 sub-ranges,
+    a thread per sub-range for the parse and again for the placement into one CSR -- and must give the identical batch;
   * the CPU emulator of the kernel source (tests/emu) is ALWAYS built with -fsanitize=undefined,bounds without recovery, so
     every run of tests/test_emu_kernel.py is a UBSan run; here only that the instrumentation is really in the library."""
 import os
@@ -26,8 +28,19 @@ def fasta_san():
     deps = srcs + [os.path.join(ROOT, "circkit_amd", "csrc", "fasta_host.h"), os.path.join(ROOT, "include", "circkit.h")]
     if not os.path.exists(BIN) or any(os.path.getmtime(d) > os.path.getmtime(BIN) for d in deps):
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                               "-fno-omit-frame-pointer", "-o", BIN] + srcs)
+                               "-fno-omit-frame-pointer", "-pthread", "-o", BIN] + srcs)
     return BIN
+
+
+@pytest.fixture(scope="module")
+def fasta_tsan():
+    """the same driver under ThreadSanitizer: the sub-range jobs of a chunk run as threads"""
+    out = os.path.join(SAN, "fasta_tsan")
+    srcs = [os.path.join(SAN, "fasta_san_main.cpp"), os.path.join(ROOT, "circkit_amd", "csrc", "fasta_host.cpp")]
+    deps = srcs + [os.path.join(ROOT, "circkit_amd", "csrc", "fasta_host.h"), os.path.join(ROOT, "include", "circkit.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-pthread", "-o", out] + srcs)
+    return out
 
 
 def texts():
@@ -109,6 +122,20 @@ def test_fasta_packer_under_asan_and_ubsan(fasta_san, tmp_path):
     # a text that does not start with '>' is an error, not a crash
     (rc, _, _, _), = run_cases(fasta_san, [(True, True, b"ACGT\n>a\nAC\n")], tmp_path)
     assert rc != 0
+
+
+def test_sub_range_parse_under_tsan(fasta_tsan, tmp_path):
+    """The chunk -> sub-ranges -> one CSR path of the CLI's parser pool with a thread per sub-range, under ThreadSanitizer:
+    no data race between the parse jobs, nor between the placement jobs (they write disjoint parts of the chunk's batch), and
+    the same batch as the single call for every split (the driver exits 3 otherwise)."""
+    path = tmp_path / "cases.bin"
+    cases = texts()[::3]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(cases)))
+        for t in cases:
+            f.write(struct.pack("<BBI", 1, 1, len(t)) + t)
+    r = subprocess.run([fasta_tsan, str(path)], capture_output=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and r.stderr == b"", r.stderr.decode(errors="replace")[-3000:]
 
 
 def test_emulator_is_built_with_ubsan():
