@@ -49,7 +49,9 @@ CK_DEV uint32_t lean_mask_window(const uint16_t* Mk, int32_t s)
 }
 
 // the 16 symbols at LDS symbol index s (first in the top bits); E[-1] .. E[nW] are valid
-CK_DEV uint32_t lean_window(const uint32_t* E, int32_t s) { return funnel(E[s >> 4], E[(s >> 4) + 1], ((uint32_t)s & 15) * 2); }
+// (a 64-bit shift, not funnel(): with a lane-varying shift the compiler turns funnel()'s "sh ? alignbit : hi" into an exec-mask
+// region around the second LDS read and a v_mul_lo_u32 by 30 for the shift amount -- a quarter-rate instruction per window)
+CK_DEV uint32_t lean_window(const uint32_t* E, int32_t s) { return lshr64(E[s >> 4], E[(s >> 4) + 1], 32 - ((uint32_t)s & 15) * 2); }
 
 // Strand from aligned chunks; returns false when a chunk holds a byte outside the alphabet (the first and last chunk also
 // hold the neighbours' bytes: a stranger there sends the record to stage A for nothing, which is harmless).
@@ -139,7 +141,7 @@ CK_DEV void lean_update(LeanBest& b, uint32_t m, uint32_t w)
 CK_DEV uint32_t lean_key_at(const uint32_t* E, uint32_t j, uint32_t b, bool fwd)
 {
     const uint32_t hi = fwd ? E[j] : rc_word<2>(E[j]), lo = fwd ? E[j + 1] : rc_word<2>(E[(int32_t)j - 1]);
-    return funnel(hi, lo, 2 * b);
+    return lshr64(hi, lo, 32 - 2 * b);
 }
 
 // Two rotations whose 16-symbol keys tie -- of one strand, or one of either strand (f1, f2: forward strand?) --, given by the
@@ -175,7 +177,9 @@ CK_DEV int lean_cmp_rot(const uint32_t* E, const LeanGeom& g, bool f1, uint32_t 
 // The record position of the forward window behind one strand's minimal rotation, from the scan's per-lane results (b) and
 // the wave minimum M: mostly one owner, possibly seen again in the extension at either end (same record position).  Several
 // owners (pure build): the smallest of their rotations, as long as they are few and no two of them equal.  -1: stage A's.
-template <bool NM>
+// K16 (pure builds, round 4): the scan compared 8-symbol prefixes (word_min_key16), M is one of them -- the positions that share
+// it are the rivals, settled by full comparison below like any other tie.
+template <bool NM, bool K16 = false>
 CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint32_t M, const LeanBest& b)
 {
     const uint32_t lane = lane_id();
@@ -190,7 +194,7 @@ CK_DEV int32_t lean_locate(const uint32_t* E, const LeanGeom& g, bool fwd, uint3
         const uint32_t j0 = readlane(b.word, l), j1 = readlane(b.second, l) != M ? j0 + 1 : g.nW;
         for (uint32_t j = j0; j < j1; j += 64) {
             const uint32_t key = lean_key_at(E, j, lane & 15, fwd);
-            uint64_t pm = ballot(lane < 16 && key == M);
+            uint64_t pm = ballot(lane < 16 && (K16 ? key >> 16 : key) == M);
             if (NM && j == j0 && popc64(pm) != 1) return -1;
             while (pm) {
                 const int32_t bit = ffs64(pm);
@@ -351,6 +355,44 @@ CK_DEV uint64_t lean_hash_finish(LeanHash& h, const uint32_t* tab, u32x4 cell, u
     return ((uint64_t)readlane((uint32_t)(v >> 32), 15) << 32) | readlane((uint32_t)v, 15);
 }
 
+// The scan of both strands in one pass over the words + the decision: strand (fwd) and the record position Q of the forward
+// window behind the winning key; 0, or 2 = stage A's (a tie the routine does not settle).  K16: 8-symbol prefixes, two per
+// v_pk_min_u16 (15 instructions per word and strand instead of 23); positions that share the minimal prefix -- one record in
+// eight at 4 kb, one in two at 20 kb of random sequence -- are lean_locate's rivals, compared in full there.  The N build's
+// prefix rule argues with 16-symbol keys and keeps them.
+template <bool NM, bool K16>
+CK_DEV int lean_scan_locate(const uint32_t* E, const LeanGeom& g, LeanBest& bF, LeanBest& bC, uint32_t& MF, uint32_t& MC, bool& fwd, int32_t& Q)
+{
+    const uint32_t lane = lane_id();
+    bF = LeanBest{}; bC = LeanBest{};
+    bF.word = bC.word = lane;
+    for (uint32_t w = lane; w < g.nW; w += 64) {
+        const uint32_t cur = E[w], nxt = E[w + 1], prv = E[(int32_t)w - 1];
+        if constexpr (K16) {
+            lean_update(bF, word_min_key16(cur, nxt), w);
+            lean_update(bC, word_min_key16(rc_word<2>(cur), rc_word<2>(prv)), w);
+        } else {
+            lean_update(bF, word_min_key<2>(cur, nxt), w);
+            lean_update(bC, word_min_key<2>(rc_word<2>(cur), rc_word<2>(prv)), w);
+        }
+    }
+    wave_min2_u32(bF.key, bC.key, MF, MC);
+    fwd = MF < MC;
+    if (MF == MC) {
+        // equal minimal keys: the two minimal rotations are compared in full (lib/src/canonicalize.rs:58-62: forward only if
+        // strictly smaller; equal = a reverse-complement palindrome, either strand's bytes are the same) -- pure build only
+        if (NM) return 2;
+        const int32_t QF = lean_locate<NM, K16>(E, g, true, MF, bF), QC = lean_locate<NM, K16>(E, g, false, MC, bC);
+        if (QF < 0 || QC < 0) return 2;
+        fwd = lean_cmp_rot(E, g, true, (uint32_t)QF, false, (uint32_t)QC) < 0;
+        Q = fwd ? QF : QC;
+    } else {
+        Q = fwd ? lean_locate<NM, K16>(E, g, true, MF, bF) : lean_locate<NM, K16>(E, g, false, MC, bC);
+        if (Q < 0) return 2;
+    }
+    return 0;
+}
+
 // One record of more than FAST_MAX_N symbols in the wave's slice.  0: done; 1: not this routine's alphabet (stage A is told);
 // 2: pure as far as seen, but a tie / equal strands / no room (stage A's general routine).
 #ifndef CK_LEAN_MIN_PREFIX
@@ -384,30 +426,16 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
         if (!build_packed<2>(a.bytes + off, n, E, E)) return 1;         // (its own extension behind the end; lean_extend repeats it)
     }
     lean_extend<NM>(g, E, Mk);
-    // both strands' minimal keys in one pass over the words
+    // both strands' minimal keys in one pass over the words, the winner located (lean_scan_locate).  Pure builds: first on
+    // 8-symbol prefixes; a record whose minimal prefix has too many owners for lean_locate (a run of 16 A, say: nine positions
+    // share AAAAAAAA) is scanned again with 16-symbol keys -- low complexity costs that record a second pass, not a trip to stage A.
     LeanBest bF, bC;
-    bF.word = bC.word = lane;
-    for (uint32_t w = lane; w < g.nW; w += 64) {
-        const uint32_t cur = E[w], nxt = E[w + 1], prv = E[(int32_t)w - 1];
-        lean_update(bF, word_min_key<2>(cur, nxt), w);
-        lean_update(bC, word_min_key<2>(rc_word<2>(cur), rc_word<2>(prv)), w);
-    }
-    uint32_t MF, MC;
-    wave_min2_u32(bF.key, bC.key, MF, MC);
-    bool fwd = MF < MC;
-    int32_t Q;
-    if (MF == MC) {
-        // equal minimal keys: the two minimal rotations are compared in full (lib/src/canonicalize.rs:58-62: forward only if
-        // strictly smaller; equal = a reverse-complement palindrome, either strand's bytes are the same) -- pure build only
-        if (NM) return 2;
-        const int32_t QF = lean_locate<NM>(E, g, true, MF, bF), QC = lean_locate<NM>(E, g, false, MC, bC);
-        if (QF < 0 || QC < 0) return 2;
-        fwd = lean_cmp_rot(E, g, true, (uint32_t)QF, false, (uint32_t)QC) < 0;
-        Q = fwd ? QF : QC;
-    } else {
-        Q = fwd ? lean_locate<NM>(E, g, true, MF, bF) : lean_locate<NM>(E, g, false, MC, bC);
-        if (Q < 0) return 2;
-    }
+    uint32_t MF = 0, MC = 0;
+    bool fwd = false;
+    int32_t Q = -1;
+    int rs = lean_scan_locate<NM, !NM>(E, g, bF, bC, MF, MC, fwd, Q);
+    if constexpr (!NM) { if (rs != 0) rs = lean_scan_locate<NM, false>(E, g, bF, bC, MF, MC, fwd, Q); }
+    if (rs != 0) return rs;
     const uint32_t M = fwd ? MF : MC;
     const uint32_t bkey = fwd ? bF.key : bC.key, bword = fwd ? bF.word : bC.word, bsecond = fwd ? bF.second : bC.second;
     const uint64_t owners = ballot(lane < g.nW && bkey == M);
