@@ -812,3 +812,54 @@ def test_randomized_lean_routine_ties(seed):
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+
+
+@pytest.mark.parametrize("with_n", [False, True])
+def test_low_complexity_records_in_a_mixed_length_batch(ctx, O, with_n):
+    """Mode-3 batches (the mixed-length kernels, bytes-only and with the XXH3, device API) full of what the pure builds' 8-symbol
+    prefix scan ties on (round 4): homopolymer runs of 8..40 A / T planted one to six times per record, microsatellites
+    (AC)n / (AAT)n, a run that wraps around the record's end -- records of 1.1..14 kb.  A record whose minimal prefix has more
+    owners than the routine compares is scanned again with 16-symbol keys; whatever is still tied is stage A's.  Bytes and
+    hashes against the oracle; with_n: 1 % N (the N builds keep 16-symbol keys)."""
+    import torch
+    rng = np.random.default_rng(404 + with_n)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for k in range(600):
+        n = int(rng.integers(1100, 14000))
+        s = acgt[rng.integers(1, 4, n)].copy() if k % 3 else acgt[rng.integers(0, 4, n)].copy()      # two thirds without A outside the plants
+        for _ in range(int(rng.integers(1, 7))):
+            run = int(rng.integers(8, 41))
+            p = int(rng.integers(0, n))
+            kind = k % 5
+            for i in range(run):
+                s[(p + i) % n] = (b"A"[0] if kind < 3 else b"T"[0]) if kind != 4 else b"AC"[i & 1]
+        if k % 11 == 0:
+            s[:12] = ord("A"); s[-9:] = ord("A")                            # a run across the record's end
+        if k % 13 == 0:
+            unit = b"AAT"
+            s[100:100 + 60] = np.frombuffer(unit * 20, dtype=np.uint8)
+        if with_n:
+            s[rng.random(n) < 0.01] = ord("N")
+        seqs.append(s.tobytes())
+    seqs += [bytes(acgt[rng.integers(0, 4, int(rng.integers(60, 900)))]) for _ in range(150)]
+    from tests import seqsets
+    data, offs = seqsets.pack(seqs)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    for want_hash in (False, True):
+        d_out = torch.zeros_like(d_bytes)
+        d_hash = torch.zeros(len(seqs), dtype=torch.int64, device=dev)
+        ctx.canonicalize_batch_device(d_bytes, d_off, len(seqs), out_bytes=d_out, out_xxh3=d_hash if want_hash else None)
+        assert ctx.batch_status() == 0 and ctx.last_batch_mode() == 3
+        got = d_out.cpu().numpy()
+        if not np.array_equal(got, exp):
+            for i in range(len(seqs)):
+                a, b = int(offs[i]), int(offs[i + 1])
+                assert got[a:b].tobytes() == exp[a:b].tobytes(), (want_hash, i, len(seqs[i]))
+        if want_hash:
+            assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    ctx.use_own_stream()
