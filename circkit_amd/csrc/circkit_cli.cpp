@@ -833,34 +833,45 @@ int main(int argc, char** argv)
         });
 
     // ---- stage 3: GPU, in input order (one ctx, one thread): canonical bytes / hashes / first-seen
-    std::thread gpu([&] {
-        const int rc = circkit_ctx_create(opt.device, &ctx);
-        init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    // One context.  (CIRCKIT_CLI_CTXS=2, `canonicalize` only: two contexts on two threads taking alternate chunks, so that the last
+    // copy-out of chunk i overlaps the first copy-in of chunk i + 1 -- measured, tools/cli_ctx_probe.sh: every call then takes
+    // twice as long, 5 GB into /dev/null 0.78-0.82 -> 0.96-1.01 s; the link and host DRAM are shared, not idle.  `uniq` always
+    // keeps one: its first-seen table is fed in input order.)
+    int n_ctx = 1;
+    if (getenv("CIRCKIT_CLI_CTXS")) { const int k = atoi(getenv("CIRCKIT_CLI_CTXS")); if (k >= 1 && k <= 2 && !uniq) n_ctx = k; }
+    circkit_ctx* ctx2 = nullptr;
+    auto gpu_stage = [&](int which) {
+        circkit_ctx*& my = which == 0 ? ctx : ctx2;
+        const int rc = circkit_ctx_create(opt.device, &my);
+        if (which == 0) init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
         if (rc != CIRCKIT_OK) die(std::string("no usable MI355X GPU (device ") + std::to_string(opt.device) + "): " +
-                                   (ctx ? circkit_last_error(ctx) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
+                                   (my ? circkit_last_error(my) : "hipGetDeviceCount failed") + "; there is no CPU fallback");
         { std::lock_guard<std::mutex> g(ctx_m); ctx_ready = true; }
         ctx_cv.notify_all();
         uint64_t base = 0;
-        for (long seq = 0; P.wait(seq, PARSED); ++seq) {
+        for (long seq = which; P.wait(seq, PARSED); seq += n_ctx) {
             Busy::Scope tb(g_gpu);
             Slot& s = P.slot[seq % Pipeline::K];
             const uint64_t n = s.batch.n();
-            s.base = base;
+            s.base = base;                          // (global record index: uniq only, one context)
             if (n) {
                 const uint64_t total = s.batch.offsets[n];
                 if (want_bytes) { s.canon.len = 0; s.canon.reserve(total + 64); }
                 if (uniq) { s.hash.resize(n); s.first_seen.resize(n); }
-                check(ctx, circkit_canonicalize_batch(ctx, s.batch.bytes.data(), s.batch.offsets.data(), n,
-                                                      want_bytes ? s.canon.data() : nullptr, nullptr, nullptr,
-                                                      uniq ? s.hash.data() : nullptr));
-                if (uniq) check(ctx, circkit_uniq_first_seen(ctx, s.hash.data(), n, base, s.first_seen.data()));
+                check(my, circkit_canonicalize_batch(my, s.batch.bytes.data(), s.batch.offsets.data(), n,
+                                                     want_bytes ? s.canon.data() : nullptr, nullptr, nullptr,
+                                                     uniq ? s.hash.data() : nullptr));
+                if (uniq) check(my, circkit_uniq_first_seen(my, s.hash.data(), n, base, s.first_seen.data()));
                 base += n;
             }
             P.set(seq, COMPUTED);
         }
         // (Giving the ring's page-locked memory back from here -- the device has nothing queued any more -- instead of leaving it
         // to the process's exit moves 0.12 s of unpinning from behind the last byte written to in front of the last join: no gain.)
-    });
+    };
+    std::thread gpu([&] { gpu_stage(0); });
+    std::thread gpu2;
+    if (n_ctx == 2) gpu2 = std::thread([&] { gpu_stage(1); });
 
     // ---- stage 4: writer, in input order (this thread) + emit workers.
     // Regular output file: the writer only lays the chunk out (a prefix sum of the record sizes), grows the file and maps
@@ -1028,6 +1039,7 @@ int main(int argc, char** argv)
     reader.join();
     for (auto& t : parsers) t.join();
     gpu.join();
+    if (gpu2.joinable()) gpu2.join();
     if (getenv("CIRCKIT_CLI_TIMING"))
         fprintf(stderr, "main() to here %.3f s;  HIP / ctx start-up %.3f s, pipeline %.3f s;  busy: read %.3f s  parse+pack %.3f (sum over %d threads)  gpu %.3f  write/layout %.3f  emit %.3f (sum over %d threads)  file write %.3f\n",
                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t_main).count(),
@@ -1056,11 +1068,13 @@ int main(int argc, char** argv)
         for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }
         lap("free pinned buffers");
         circkit_ctx_destroy(ctx);
+        if (ctx2) circkit_ctx_destroy(ctx2);
         lap("ctx destroy");
         fflush(nullptr); _exit(0);
     }
     if (!getenv("CIRCKIT_CLI_CLEAN_EXIT")) { fflush(nullptr); _exit(0); }
     for (Slot& sl : P.slot) { sl.batch.bytes.~ByteBuf(); new (&sl.batch.bytes) ckhost::ByteBuf(); sl.canon.~ByteBuf(); new (&sl.canon) ckhost::ByteBuf(); }   // pinned memory goes before the ctx
     circkit_ctx_destroy(ctx);
+    if (ctx2) circkit_ctx_destroy(ctx2);
     return 0;
 }
