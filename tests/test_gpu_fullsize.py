@@ -251,6 +251,23 @@ def test_bench_two_ranks_rehearsal_checks_first_seen_across_ranks():
     assert chk["oracle_slice"]
 
 
+def test_bench_two_ranks_rehearsal_default_workload():
+    """The line the driver's scaling run asks for -- `bench.py --gpus N`, default workload, started WITHOUT a launcher around it --
+    rehearsed with two ranks on this one GPU over gloo: the parent starts its own ranks, every rank's shard is its own range of
+    the job's seed stream, MAX-over-ranks timing, one JSON line from rank 0, clean exit of both ranks."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"CIRCKIT_BENCH_SHARE_GPU": "1", "CIRCKIT_BENCH_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--records", "300000", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["records_total"] == 600000 and line["scaling"] == "weak"
+    assert line["roofline"]["frac"] > 0 and "other_workloads" not in line and "cli" not in line
+
+
 @pytest.mark.parametrize("workload", [["--workload", "uniq"], ["--workload", "mixed", "--with-hash"]])
 def test_bench_hash_only_lines(workload):
     """bench.py --hash-only (`circkit uniq` without --canonicalize: no canonical bytes are written, SURVEY 8d's L + 16 bytes per
