@@ -155,10 +155,10 @@ CK_DEV void group_hash_put(uint32_t* slot, uint64_t k0, uint64_t k1, u32x4 cell,
 template <int GROUP>
 CK_DEV void group_hash_merge(const CanonArgs& a, const uint32_t* lut, const uint32_t* ghc, const uint32_t* slots, uint32_t rec0)
 {
-    static_assert(GROUP == 16, "one lane per (record, accumulator pair)");
+    static_assert(GROUP <= 16, "one lane per (record, accumulator pair)");
     const uint32_t t = lane_id(), r = t >> 2, j = t & 3;
-    const uint32_t* s = slots + r * GH_STRIDE_DW;
-    const bool valid = s[130] != 0;
+    const uint32_t* s = slots + (r < (uint32_t)GROUP ? r : 0u) * GH_STRIDE_DW;      // (smaller groups: the upper lanes idle)
+    const bool valid = r < (uint32_t)GROUP && s[130] != 0;
     const uint32_t n = valid ? s[128] : 64u, idx = valid ? s[129] : 0u;       // (a dummy that keeps the reads inside the slot)
     const u32x4 cl = lds_load16(ghc + 12 * j), cm = lds_load16(ghc + 12 * j + 4), ci = lds_load16(ghc + 12 * j + 8);
     uint64_t a0 = ((uint64_t)ci.y << 32) | ci.x, a1 = ((uint64_t)ci.w << 32) | ci.z;

@@ -145,7 +145,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
 {
     static_assert(!ALPHA || !AUX, "index / strand outputs: the 4-bit records take the LDS tiers");
     static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
-    static_assert(!GH || (HASH && C::RPW == 1 && C::GROUP == 16), "the group merger takes 16 records, one per wave");
+    static_assert(!GH || (HASH && C::RPW == 1 && C::GROUP <= 16), "the group merger takes up to 16 records, one per wave");
     constexpr int D = C::NBUF - 1;                    // groups in flight
     // the touches pay in the builds with the fused XXH3, which are bound by instruction issue (same box, 10M x 1 kb: bytes + hash
     // 4.16 -> 4.05 ms); the bytes-only build sits on the memory system and LOSES when its loads go out earlier (3.60 -> 4.00 ms

@@ -480,20 +480,20 @@ CK_MIXED_KERNEL(canon_mixed_nh_kernel, true, true, CK_MIXED_NM_VGPR)
 // ALPHA (ROWS = 1, no index / strand outputs): the build for batches with MODE_ALPHA -- records with N or '-' take the
 // 4-bit register routine inside the staged loop.  The builds without it answer for every other batch, MODE_ALPHA or not.
 template <class StreamC, bool HASH, bool AUX, bool PERSIST, bool ALPHA = false>
-__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 16 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
+__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 8 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
                                                                                                              uint32_t host_mode, uint32_t nvb)
 {
     const uint32_t bm = batch_mode(mode, host_mode);
     if ((bm & 3) != (uint32_t)StreamC::ROWS) return;                             // the other build (or none) has this batch
     constexpr bool HAS_ALPHA_TWIN = StreamC::ROWS == 1 && !AUX;
     if (HAS_ALPHA_TWIN && ((bm & MODE_ALPHA) != 0) != ALPHA) return;
-    constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && StreamC::RPW == 1 && StreamC::GROUP == 16;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<16>() : 0)];
+    constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && StreamC::RPW == 1 && StreamC::GROUP <= 16;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<(int)StreamC::GROUP>() : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + ck::FAST_LUT_DW;
     uint32_t* gh = lds + StreamC::LDS_DW;
     ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
-    if (GH) ck::group_hash_init(gh + 2 * 16 * ck::GH_STRIDE_DW, threadIdx.x);
+    if (GH) ck::group_hash_init(gh + 2 * StreamC::GROUP * ck::GH_STRIDE_DW, threadIdx.x);
     if (!PERSIST) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
