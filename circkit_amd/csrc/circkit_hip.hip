@@ -269,7 +269,7 @@ __global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __res
 {
     __shared__ uint32_t blk[3];
     if (threadIdx.x < 3) blk[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 3) { counters[0] = 0; counters[1] = 0; counters[3] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 3) { counters[0] = 0; counters[1] = 0; counters[3] = 0; counters[16] = 0; counters[17] = 0; }      // ([16], [17]: the mixed N builds' segment ticket -- self-zeroing, zeroed here as well)
     __syncthreads();
     const uint32_t shift = count_shift(n);
     const uint64_t ns = count_samples(n);
