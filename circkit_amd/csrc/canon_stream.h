@@ -210,7 +210,11 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         // bound of what leaner scalar bookkeeping at the head of the loop could buy
         s = (uint64_t)(oor ? 0 : gf) * C::GROUP * 1000; e = s + C::GROUP * 1000; o0 = (uint64_t)ra * 1000; o1 = o0 + 1000; o2 = o1 + 1000;
 #else
+#ifdef CK_STREAM_INDEXED
+        sload_group<(int)C::GROUP>(a.offsets + (uint64_t)(oor ? 0u : gf) * C::GROUP, a.offsets + ra, s, e, o0, o1, o2);
+#else
         sload_group<(int)C::GROUP>(oor ? a.offsets : p_grp, p_rec, s, e, o0, o1, o2);
+#endif
 #endif
 #ifdef CK_DEBUG_POISON
         stream_poison<C>(ring + free_dw);
@@ -221,12 +225,18 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         const StreamGroup fut = stream_issue<C>(a, sb, oor, s, e, ring + free_dw, c16);
         // the next iteration's group to prefetch
         gf += nblocks;
+#ifndef CK_STREAM_INDEXED
         p_grp += stride;
+#endif
         oor = (n_staged - 1u - gf) >> 31;
         if constexpr (PF) {
             // the offsets the next iteration loads: the span of that group -- its first offset (lanes 0..31) and the one behind
             // its last (lanes 32..63: the next 128 bytes) -- which are also the lines of this wave's record two iterations on
+#ifdef CK_STREAM_INDEXED
+            glds4_touch(ring + (C::LDS_DW - 64), a.offsets + (uint64_t)(oor ? 0u : gf) * C::GROUP, pf_off);
+#else
             glds4_touch(ring + (C::LDS_DW - 64), oor ? a.offsets : p_grp, pf_off);
+#endif
         }
         const uint32_t* img = ring + img_dw;
         uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + w) * GH_STRIDE_DW : nullptr;
@@ -327,7 +337,9 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         free_dw = img_dw;
         img_dw = img_dw + C::BUF_DW == C::NBUF * C::BUF_DW ? 0 : img_dw + C::BUF_DW;
         ra += nblocks * C::GROUP;
+#ifndef CK_STREAM_INDEXED
         p_rec += stride;
+#endif
     }
     if constexpr (GH) {
         if (it > 0 && w == ((it - 1) & (C::WPB - 1))) {             // the last group's hashes (behind the loop's final barrier)
