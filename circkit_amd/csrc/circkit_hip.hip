@@ -722,15 +722,18 @@ __device__ __forceinline__ bool uniq_fold_local(UniqSlot* t, uint64_t mask, uint
         if (++probes > mask) return false;                  // table full
     }
 }
-__global__ __launch_bounds__(256) void uniq_resolve_insert_kernel(const uint64_t* __restrict__ hash, uint64_t n, UniqSlot* t, uint64_t mask, uint32_t* status)
+__global__ __launch_bounds__(256) void uniq_resolve_insert_kernel(const uint64_t* __restrict__ hash, uint64_t n, UniqSlot* t, uint64_t mask, uint32_t* status,
+                                                                  const uint32_t* only_if = nullptr)
 {
+    if (only_if && *only_if == 0) return;                   // (the bucketed resolve's fallback: runs only when a bucket was too big)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         if (!uniq_fold_local(t, mask, hash[i], (uint32_t)i)) atomicAdd(status, 1u);
 }
 __global__ __launch_bounds__(256) void uniq_resolve_lookup_kernel(const uint64_t* __restrict__ hash, uint64_t n, const UniqSlot* __restrict__ t, uint64_t mask,
-                                                                  uint64_t* first_seen, uint8_t* keep, uint64_t base)
+                                                                  uint64_t* first_seen, uint8_t* keep, uint64_t base, const uint32_t* only_if = nullptr)
 {
+    if (only_if && *only_if == 0) return;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t h = hash[i];
@@ -870,13 +873,161 @@ __global__ __launch_bounds__(256) void uniq_gather_kernel(const uint64_t* __rest
 }
 
 // every slot = {EMPTY, EMPTY}: 16 bytes per thread and trip; also zeroes the overflow counter
-__global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t slots, uint32_t* overflow)
+__global__ __launch_bounds__(256) void uniq_clear_kernel(UniqSlot* t, uint64_t slots, uint32_t* overflow, const uint32_t* only_if = nullptr)
 {
+    if (only_if && *only_if == 0) return;
     typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
     if (overflow && blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += stride)
         *reinterpret_cast<v2*>(t + i) = v2{ UNIQ_EMPTY, UNIQ_EMPTY };
+}
+
+// ---- circkit_uniq_resolve_device in LDS-sized buckets (round 4) --------------------------------------------------------------
+// The open-addressing table in HBM costs every key a scattered 16-byte read and one or two memory-side atomics (10M keys:
+// clear 0.05 + insert 0.48 + lookup 0.22 ms).  A shard that is resolved in ONE call needs no table that outlives it: the keys
+// are partitioned by their top bits into buckets of ~1300..2600 keys (a counting pass, two small scans, a scatter of
+// {hash, local index} rows -- no global atomic anywhere: every workgroup owns a contiguous range of the keys and its own column
+// of the count matrix), and each bucket is resolved by one workgroup in a 4096-slot table in LDS (64-bit LDS compare-and-swap
+// on the key, LDS atomic min on the index).  What stays scattered is the answer: first_seen[i] and keep[i] go to the record's
+// own place.  A bucket with more than BKT_MAX keys (all records equal, say) raises a flag and the whole shard takes the HBM
+// table behind it -- same answers; its three kernels return at once otherwise.  Scratch: the table's own memory (rows, count
+// matrix, bucket totals and bases all fit the slots circkit_uniq_reset sizes for n keys).
+#ifndef CK_BKT_NW
+#define CK_BKT_NW 512
+#endif
+constexpr uint32_t BKT_NW = CK_BKT_NW, BKT_SLOTS = 4096, BKT_MAX = 3072, BKT_KEYS = 2600, BKT_MAX_LOG2 = 13;      // (mean bucket 1300..2600 keys; 2200 -- twice the buckets at 10M keys -- measured 1 % slower)
+__device__ __forceinline__ uint32_t bkt_of(uint64_t h, uint32_t log2b) { return (uint32_t)(h >> (64 - log2b)); }
+// counts[w][b] = keys of workgroup w's range in bucket b; also zeroes the fallback flag and the table-overflow counter
+__global__ __launch_bounds__(1024) void uniq_bkt_count_kernel(const uint64_t* __restrict__ hash, uint64_t n, uint64_t per, uint32_t log2b, uint32_t* counts,
+                                                              uint32_t* flag, uint32_t* overflow)
+{
+    extern __shared__ uint32_t bkt_lds[];
+    const uint32_t B = 1u << log2b;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) bkt_lds[b] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *flag = 0; *overflow = 0; }
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += 1024) atomicAdd(&bkt_lds[bkt_of(hash[i], log2b)], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) counts[(uint64_t)blockIdx.x * B + b] = bkt_lds[b];
+}
+// per bucket: exclusive prefix of the counts over the workgroups (in place), the bucket's total.  A workgroup takes 64 buckets,
+// sixteen threads per bucket with a 32nd of the column each (one thread per bucket walking all 512 counts: 65 us of latency)
+__global__ __launch_bounds__(1024) void uniq_bkt_colscan_kernel(uint32_t* counts, uint32_t B, uint32_t* tot)
+{
+    __shared__ uint32_t seg[16][64];
+    constexpr uint32_t PER = BKT_NW / 16;
+    const uint32_t bl = threadIdx.x & 63, sg = threadIdx.x >> 6, b = blockIdx.x * 64 + bl;      // (B is a multiple of 64)
+    uint32_t sum = 0;
+    for (uint32_t w = sg * PER; w < (sg + 1) * PER; ++w) sum += counts[(uint64_t)w * B + b];
+    seg[sg][bl] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < sg; ++k) run += seg[k][bl];
+    for (uint32_t w = sg * PER; w < (sg + 1) * PER; ++w) {
+        const uint64_t k = (uint64_t)w * B + b;
+        const uint32_t cnt = counts[k];
+        counts[k] = run;
+        run += cnt;
+    }
+    if (sg == 15) tot[b] = run;
+}
+// base[b] = first row of bucket b, base[B] = n (one workgroup; B <= 8192)
+__global__ __launch_bounds__(1024) void uniq_bkt_basescan_kernel(const uint32_t* __restrict__ tot, uint32_t B, uint32_t* base)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t items = (B + 1023) / 1024, b0 = threadIdx.x * items;
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < items; ++k) if (b0 + k < B) sum += tot[b0 + k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {                   // inclusive scan of the partial sums
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (uint32_t k = 0; k < items; ++k) if (b0 + k < B) { base[b0 + k] = run; run += tot[b0 + k]; }
+    if (threadIdx.x == 1023) base[B] = part[1023];
+}
+// rows[base[b] + ...] = {hash, local index}; a workgroup's keys of bucket b start at base[b] + its prefix in the count matrix
+__global__ __launch_bounds__(1024) void uniq_bkt_scatter_kernel(const uint64_t* __restrict__ hash, uint64_t n, uint64_t per, uint32_t log2b,
+                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ base, uint64_t* rows)
+{
+    extern __shared__ uint32_t bkt_lds[];
+    const uint32_t B = 1u << log2b;
+    for (uint32_t b = threadIdx.x; b < B; b += 1024) bkt_lds[b] = base[b] + counts[(uint64_t)blockIdx.x * B + b];
+    __syncthreads();
+    const uint64_t i0 = (uint64_t)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+    constexpr int U = 4;                                    // keys in flight per thread (one at a time the loop is a chain of load latencies)
+    uint64_t i = i0 + threadIdx.x;
+    for (; i + (U - 1) * 1024 < i1; i += U * 1024) {
+        uint64_t h[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) h[u] = hash[i + u * 1024];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t pos = atomicAdd(&bkt_lds[bkt_of(h[u], log2b)], 1u);
+            *reinterpret_cast<v2*>(rows + 2 * (uint64_t)pos) = v2{ h[u], i + u * 1024 };
+        }
+    }
+    for (; i < i1; i += 1024) {
+        const uint64_t h = hash[i];
+        const uint32_t pos = atomicAdd(&bkt_lds[bkt_of(h, log2b)], 1u);
+        *reinterpret_cast<v2*>(rows + 2 * (uint64_t)pos) = v2{ h, i };
+    }
+}
+// one workgroup per bucket: smallest local index per key in an LDS table, then every row's answer to its record's place
+#ifndef BKT_RESOLVE_T
+#define BKT_RESOLVE_T 1024     // threads per bucket: 48 KB of LDS allow two workgroups per CU -- at 1024 threads that is every wave slot (256: 12 of 32)
+#endif
+__global__ __launch_bounds__(BKT_RESOLVE_T) void uniq_bkt_resolve_kernel(const uint64_t* __restrict__ rows, const uint32_t* __restrict__ base, uint64_t base_index,
+                                                               uint64_t* first_seen, uint8_t* keep, uint32_t* flag)
+{
+    __shared__ unsigned long long keys[BKT_SLOTS];
+    __shared__ uint32_t idx[BKT_SLOTS], special;
+    const uint32_t r0 = base[blockIdx.x], cnt = base[blockIdx.x + 1] - r0;
+    if (cnt == 0) return;
+    if (cnt > BKT_MAX) { if (threadIdx.x == 0) atomicExch(flag, 1u); return; }      // the HBM table has this shard (every record of it)
+    for (uint32_t s = threadIdx.x; s < BKT_SLOTS; s += BKT_RESOLVE_T) { keys[s] = UNIQ_EMPTY; idx[s] = 0xFFFFFFFFu; }
+    if (threadIdx.x == 0) special = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < cnt; r += BKT_RESOLVE_T) {
+        const UniqSlot row = uniq_peek(reinterpret_cast<const UniqSlot*>(rows) + r0 + r);
+        const uint64_t h = row.key;
+        const uint32_t i = (uint32_t)row.val;
+        if (h == UNIQ_EMPTY) { atomicMin(&special, i); continue; }
+        uint32_t s = (uint32_t)(h ^ (h >> 29)) & (BKT_SLOTS - 1);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
+            if (old == UNIQ_EMPTY || old == h) { atomicMin(&idx[s], i); break; }
+            s = (s + 1) & (BKT_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < cnt; r += BKT_RESOLVE_T) {
+        const UniqSlot row = uniq_peek(reinterpret_cast<const UniqSlot*>(rows) + r0 + r);
+        const uint64_t h = row.key;
+        const uint32_t i = (uint32_t)row.val;
+        uint32_t m;
+        if (h == UNIQ_EMPTY) m = special;
+        else {
+            uint32_t s = (uint32_t)(h ^ (h >> 29)) & (BKT_SLOTS - 1);
+            while (keys[s] != h) s = (s + 1) & (BKT_SLOTS - 1);
+            m = idx[s];
+        }
+        first_seen[i] = base_index + m;                  // (the one scattered store per record; keep[] follows from it, coalesced)
+    }
+}
+// keep[i] = 1 iff record i is the first with its hash
+__global__ __launch_bounds__(256) void uniq_keep_kernel(const uint64_t* __restrict__ first_seen, uint64_t n, uint64_t base, uint8_t* keep, const uint32_t* skip_if)
+{
+    if (skip_if && *skip_if != 0) return;                   // (the fallback writes its own)
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) keep[i] = first_seen[i] == base + i;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1828,9 +1979,9 @@ int circkit_xxh3_batch_device(circkit_ctx* c, const uint8_t* d_bytes, const uint
 #ifndef CK_UNIQ_LOAD_PCT
 #define CK_UNIQ_LOAD_PCT 70       // circkit_uniq_reset sizes the table for at most this load with `expected_keys` distinct keys
 #endif
-int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
+// the table sized (allocated) for `expected_keys` distinct keys at CK_UNIQ_LOAD_PCT; contents untouched
+static int uniq_size(circkit_ctx* c, uint64_t expected_keys)
 {
-    if (!c) return CIRCKIT_ERR_INVALID_ARG;
     CK_HIP(c, hipSetDevice(c->device));
     uint64_t cap = 1024;
     while (cap * CK_UNIQ_LOAD_PCT < expected_keys * 100) cap <<= 1;
@@ -1840,6 +1991,14 @@ int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
         if ((rc = grow(c, c->d_table, cap + 1))) return rc;
         c->uniq_mask = cap - 1;
     }
+    return CIRCKIT_OK;
+}
+int circkit_uniq_reset(circkit_ctx* c, uint64_t expected_keys)
+{
+    if (!c) return CIRCKIT_ERR_INVALID_ARG;
+    const int rcs = uniq_size(c, expected_keys);
+    if (rcs) return rcs;
+    const uint64_t cap = c->uniq_mask + 1;
     hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_table, cap + 1, c->d_counters + 4);
     CK_HIP(c, hipGetLastError());
     c->uniq_count = 0;
@@ -1999,6 +2158,46 @@ int circkit_uniq_resolve_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t
 {
     if (!c || (n && (!d_hash || !d_first_seen))) return CIRCKIT_ERR_INVALID_ARG;
     if (n >= 0xFFFFFFFFull) return fail(c, CIRCKIT_ERR_INVALID_ARG, "circkit_uniq_resolve_device: n must be < 2^32 - 1");     // before the table is touched
+#ifndef CK_BKT_KEYS
+#define CK_BKT_KEYS BKT_KEYS
+#endif
+#ifndef CK_UNIQ_BUCKET_MIN
+#define CK_UNIQ_BUCKET_MIN (1u << 19)      // shards below this take the HBM table directly (the bucketed path is five launches)
+#endif
+    static const bool no_buckets = getenv("CIRCKIT_UNIQ_NO_BUCKETS") != nullptr;
+    if (n >= CK_UNIQ_BUCKET_MIN && !no_buckets) {
+        // LDS-sized buckets (see uniq_bkt_*_kernel); the table's memory is the scratch, the table itself only the fallback
+        int rc = uniq_size(c, n);
+        if (rc) return rc;
+        uint32_t log2b = 6;
+        while (log2b < BKT_MAX_LOG2 && ((uint64_t)CK_BKT_KEYS << log2b) < n) ++log2b;
+        const uint32_t B = 1u << log2b;
+        const uint64_t per = (n + BKT_NW - 1) / BKT_NW;
+        uint8_t* scratch = reinterpret_cast<uint8_t*>(c->d_table);
+        uint64_t* rows = reinterpret_cast<uint64_t*>(scratch);
+        uint32_t* counts = reinterpret_cast<uint32_t*>(scratch + ((n * 16 + 255) & ~255ull));
+        uint32_t* tot = counts + (uint64_t)BKT_NW * B;
+        uint32_t* base = tot + B;
+        if ((uint64_t)(reinterpret_cast<uint8_t*>(base + B + 1) - scratch) > (c->uniq_mask + 2) * sizeof(UniqSlot))
+            return fail(c, CIRCKIT_ERR_INVALID_ARG, "internal: bucket scratch does not fit the table");
+        uint32_t* flag = c->d_counters + 20;
+        hipLaunchKernelGGL(uniq_bkt_count_kernel, dim3(BKT_NW), dim3(1024), B * 4, c->stream, d_hash, n, per, log2b, counts, flag, c->d_counters + 4);
+        hipLaunchKernelGGL(uniq_bkt_colscan_kernel, dim3(B / 64), dim3(1024), 0, c->stream, counts, B, tot);
+        hipLaunchKernelGGL(uniq_bkt_basescan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)tot, B, base);
+        hipLaunchKernelGGL(uniq_bkt_scatter_kernel, dim3(BKT_NW), dim3(1024), B * 4, c->stream, d_hash, n, per, log2b, (const uint32_t*)counts, (const uint32_t*)base, rows);
+        hipLaunchKernelGGL(uniq_bkt_resolve_kernel, dim3(B), dim3(BKT_RESOLVE_T), 0, c->stream, (const uint64_t*)rows, (const uint32_t*)base, base_index, d_first_seen, d_keep, flag);
+        if (d_keep) hipLaunchKernelGGL(uniq_keep_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, (const uint64_t*)d_first_seen, n, base_index, d_keep, (const uint32_t*)flag);
+        // the fallback (a bucket beyond BKT_MAX keys): the HBM table over the whole shard; three launches that return at once otherwise
+        hipLaunchKernelGGL(uniq_clear_kernel, dim3(N_CU * 8), dim3(256), 0, c->stream, c->d_table, c->uniq_mask + 2, (uint32_t*)nullptr, (const uint32_t*)flag);
+        hipLaunchKernelGGL(uniq_resolve_insert_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, c->d_table, c->uniq_mask, c->d_counters + 4, (const uint32_t*)flag);
+        hipLaunchKernelGGL(uniq_resolve_lookup_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, (const UniqSlot*)c->d_table, c->uniq_mask,
+                           d_first_seen, d_keep, base_index, (const uint32_t*)flag);
+        CK_HIP(c, hipGetLastError());
+        c->uniq_local = true;
+        c->uniq_count = n;
+        c->uniq_lost = false;
+        return CIRCKIT_OK;
+    }
     int rc = circkit_uniq_reset(c, n);
     if (rc || n == 0) return rc;
     hipLaunchKernelGGL(uniq_resolve_insert_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, d_hash, n, c->d_table, c->uniq_mask, c->d_counters + 4);

@@ -253,3 +253,55 @@ def test_host_batch_staging_grows_and_shrinks_with_the_batch(O):
             _, st, idx = seqsets.expected(O, seqs[i])
             assert int(got["strand"][i]) == st and int(got["index"][i]) == idx, (count, i)
     ctx.close()
+
+
+def _expected_first_seen(h):
+    """smallest index per value (numpy): order of first occurrence"""
+    order = np.argsort(h, kind="stable")
+    hs = h[order]
+    first_of_group = np.r_[True, hs[1:] != hs[:-1]]
+    group_first_idx = order[first_of_group]                     # stable sort: the first of each run is the smallest index
+    group_id = np.cumsum(first_of_group) - 1
+    fs = np.empty(len(h), dtype=np.int64)
+    fs[order] = group_first_idx[group_id]
+    return fs
+
+
+@pytest.mark.parametrize("shape", ["random", "empty_key", "one_bucket", "all_equal", "small"])
+def test_resolve_in_lds_buckets_and_its_fallback(shape):
+    """circkit_uniq_resolve_device (round 4): shards of 2^19 keys and more are resolved in LDS-sized buckets (count matrix ->
+    scans -> scatter of {hash, index} rows -> one workgroup per bucket); a bucket beyond 3072 keys sends the whole shard to the
+    HBM table instead.  first_seen / keep against a NumPy restatement of src/uniq.rs:47-48 for: random keys with ~3x
+    duplication, the table's EMPTY marker (~0) as a key, keys that all share their top bits (one bucket: fallback), all keys
+    equal (fallback), and a shard below the threshold (the HBM table directly)."""
+    import torch
+    import circkit_amd
+    rng = np.random.default_rng(77)
+    n = {"small": 200_000}.get(shape, 3_000_000)
+    if shape == "all_equal":
+        h = np.full(n, 0x1234567890ABCDEF, dtype=np.uint64)
+    else:
+        h = rng.integers(0, 1 << 63, size=n // 3, dtype=np.uint64)[rng.integers(0, n // 3, size=n)] * np.uint64(2) + np.uint64(1)
+        if shape == "empty_key":
+            h[rng.integers(0, n, size=1000)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            h[5] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        if shape == "one_bucket":
+            h = (h >> np.uint64(20)) | np.uint64(0xABCDE00000000000)
+    exp = _expected_first_seen(h)
+    c = circkit_amd.Context(0)
+    dev = torch.device("cuda", 0)
+    c.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_h = torch.from_numpy(h.view(np.int64)).to(dev)
+    for base in (0, 7_000_000_000):
+        fs = torch.full((n,), -1, dtype=torch.int64, device=dev)
+        keep = torch.full((n,), 7, dtype=torch.uint8, device=dev)
+        c.uniq_resolve_device(d_h, n, base, fs, keep)
+        c.uniq_status()
+        got = fs.cpu().numpy()
+        assert np.array_equal(got, exp + base), (shape, base, int((got != exp + base).sum()))
+        assert np.array_equal(keep.cpu().numpy(), (exp == np.arange(n)).astype(np.uint8))
+    # the streaming table still works behind a resolve (it refuses until reset, then takes a stream)
+    c.uniq_reset(1000)
+    out = c.uniq_first_seen(np.array([5, 6, 5], dtype=np.uint64), base_index=10)
+    assert out.tolist() == [10, 11, 10]
+    c.close()
