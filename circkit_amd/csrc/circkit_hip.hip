@@ -995,23 +995,33 @@ __global__ __launch_bounds__(BKT_RESOLVE_T) void uniq_bkt_resolve_kernel(const u
     for (uint32_t s = threadIdx.x; s < BKT_SLOTS; s += BKT_RESOLVE_T) { keys[s] = UNIQ_EMPTY; idx[s] = 0xFFFFFFFFu; }
     if (threadIdx.x == 0) special = 0xFFFFFFFFu;
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < cnt; r += BKT_RESOLVE_T) {
-        const UniqSlot row = uniq_peek(reinterpret_cast<const UniqSlot*>(rows) + r0 + r);
-        const uint64_t h = row.key;
-        const uint32_t i = (uint32_t)row.val;
-        if (h == UNIQ_EMPTY) { atomicMin(&special, i); continue; }
+    // a thread's rows stay in registers between the two passes (cnt <= BKT_MAX = 3 x 1024)
+    constexpr uint32_t RPT = (BKT_MAX + BKT_RESOLVE_T - 1) / BKT_RESOLVE_T;
+    uint64_t hk[RPT];
+    uint32_t ik[RPT];
+#pragma unroll
+    for (uint32_t k = 0; k < RPT; ++k) {
+        const uint32_t r = threadIdx.x + k * BKT_RESOLVE_T;
+        hk[k] = 0; ik[k] = 0xFFFFFFFFu;
+        if (r < cnt) { const UniqSlot row = uniq_peek(reinterpret_cast<const UniqSlot*>(rows) + r0 + r); hk[k] = row.key; ik[k] = (uint32_t)row.val; }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < RPT; ++k) {
+        if (ik[k] == 0xFFFFFFFFu) continue;
+        const uint64_t h = hk[k];
+        if (h == UNIQ_EMPTY) { atomicMin(&special, ik[k]); continue; }
         uint32_t s = (uint32_t)(h ^ (h >> 29)) & (BKT_SLOTS - 1);
         for (;;) {
             const unsigned long long old = atomicCAS(&keys[s], (unsigned long long)UNIQ_EMPTY, (unsigned long long)h);
-            if (old == UNIQ_EMPTY || old == h) { atomicMin(&idx[s], i); break; }
+            if (old == UNIQ_EMPTY || old == h) { atomicMin(&idx[s], ik[k]); break; }
             s = (s + 1) & (BKT_SLOTS - 1);
         }
     }
     __syncthreads();
-    for (uint32_t r = threadIdx.x; r < cnt; r += BKT_RESOLVE_T) {
-        const UniqSlot row = uniq_peek(reinterpret_cast<const UniqSlot*>(rows) + r0 + r);
-        const uint64_t h = row.key;
-        const uint32_t i = (uint32_t)row.val;
+#pragma unroll
+    for (uint32_t k = 0; k < RPT; ++k) {
+        if (ik[k] == 0xFFFFFFFFu) continue;
+        const uint64_t h = hk[k];
         uint32_t m;
         if (h == UNIQ_EMPTY) m = special;
         else {
@@ -1019,7 +1029,7 @@ __global__ __launch_bounds__(BKT_RESOLVE_T) void uniq_bkt_resolve_kernel(const u
             while (keys[s] != h) s = (s + 1) & (BKT_SLOTS - 1);
             m = idx[s];
         }
-        first_seen[i] = base_index + m;                  // (the one scattered store per record; keep[] follows from it, coalesced)
+        first_seen[ik[k]] = base_index + m;             // (the one scattered store per record; keep[] follows from it, coalesced)
     }
 }
 // keep[i] = 1 iff record i is the first with its hash
