@@ -2175,7 +2175,9 @@ int circkit_uniq_resolve_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t
 #define CK_UNIQ_BUCKET_MIN (1u << 19)      // shards below this take the HBM table directly (the bucketed path is five launches)
 #endif
     static const bool no_buckets = getenv("CIRCKIT_UNIQ_NO_BUCKETS") != nullptr;
-    if (n >= CK_UNIQ_BUCKET_MIN && !no_buckets) {
+    // (shards beyond 2600 x 8192 = 21M keys would overfill their buckets -- the count / scatter histograms hold 8192 bins in LDS --
+    // and take the HBM table directly, like the small ones)
+    if (n >= CK_UNIQ_BUCKET_MIN && n <= ((uint64_t)CK_BKT_KEYS << BKT_MAX_LOG2) && !no_buckets) {
         // LDS-sized buckets (see uniq_bkt_*_kernel); the table's memory is the scratch, the table itself only the fallback
         int rc = uniq_size(c, n);
         if (rc) return rc;

@@ -173,7 +173,8 @@ int circkit_uniq_gather_device(circkit_ctx* ctx, const uint64_t* d_answers, cons
  * d_keep[i] (nullable, uint8) = 1 iff d_first_seen[i] == base_index + i -- the reference's per-record decision "emit,
  * or write a table row" (src/uniq.rs:47-62).  n < 2^32 - 1.  The table's contents are private to the call (it keeps
  * shard-local indices in a layout of its own): circkit_uniq_insert_* / _lookup_device refuse to touch it until the next
- * circkit_uniq_reset. */
+ * circkit_uniq_reset.  (Shards of 2^19 .. 21M keys are resolved in LDS-sized buckets with the table's memory as scratch --
+ * same answers, no table contents at all afterwards; CIRCKIT_UNIQ_NO_BUCKETS=1 in the environment keeps the table path.) */
 int circkit_uniq_resolve_device(circkit_ctx* ctx, const uint64_t* d_hash, uint64_t n, uint64_t base_index,
                                 uint64_t* d_first_seen, uint8_t* d_keep);
 /* reset / insert / lookup / resolve only enqueue work.  circkit_uniq_status waits for it and fails with CIRCKIT_ERR_OOM when

@@ -267,7 +267,7 @@ def _expected_first_seen(h):
     return fs
 
 
-@pytest.mark.parametrize("shape", ["random", "empty_key", "one_bucket", "all_equal", "small"])
+@pytest.mark.parametrize("shape", ["random", "empty_key", "one_bucket", "all_equal", "small", "threshold", "beyond"])
 def test_resolve_in_lds_buckets_and_its_fallback(shape):
     """circkit_uniq_resolve_device (round 4): shards of 2^19 keys and more are resolved in LDS-sized buckets (count matrix ->
     scans -> scatter of {hash, index} rows -> one workgroup per bucket); a bucket beyond 3072 keys sends the whole shard to the
@@ -277,7 +277,7 @@ def test_resolve_in_lds_buckets_and_its_fallback(shape):
     import torch
     import circkit_amd
     rng = np.random.default_rng(77)
-    n = {"small": 200_000}.get(shape, 3_000_000)
+    n = {"small": 200_000, "threshold": 1 << 19, "beyond": 22_000_000}.get(shape, 3_000_000)       # (beyond 21M keys: the HBM table again)
     if shape == "all_equal":
         h = np.full(n, 0x1234567890ABCDEF, dtype=np.uint64)
     else:
