@@ -234,6 +234,14 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 // have reported the same mode twice: then only that mode's build is launched (launch_canon, MODE_GUESS).
 using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
 using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
+// The builds with the fused XXH3 (ROWS = 1) run 8-wave workgroups, four per CU, groups of 8 records (round 4): they are bound by
+// instruction issue, and four independent barrier domains per CU leave fewer issue slots empty than two -- hash only -3 % on
+// every box measured, bytes + hash -2 % .. 0.  The bytes-only builds are bound by the memory system and keep 16 waves (-1 % on one
+// box, +3.5 % on another).
+#ifndef CK_STREAM_WPB_HASH
+#define CK_STREAM_WPB_HASH 8
+#endif
+using StreamCH = ck::StreamCfg<CK_STREAM_WPB_HASH, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
 // The build with every output (index / strand / forward-only) needs ~100 SGPRs: at 16 waves per workgroup only one
 // workgroup would fit a CU (measured: 5.1-5.7 ms instead of 3.4-4.0).  It keeps 4-wave workgroups (2 records per
 // wave), where SGPRs only cost a seventh wave per SIMD.
@@ -1302,7 +1310,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const uint32_t seen = *c->h_mode;
         const uint32_t expect = host_mode ? host_mode & 3 : ((seen & 3) ? seen & 3 : 1u);
         const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
-        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64);
+        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64), block_h(StreamCH::WPB * 64);
         // (rows, alphabet) builds: ROWS = 1 lean, ROWS = 1 with the 4-bit routine, ROWS = 2.  The host's answer launches
         // exactly one; a device-side decision launches all three, full-size where the previous batch's mode says it will run
         const uint32_t expect_alpha = host_mode ? host_mode & MODE_ALPHA : seen & MODE_ALPHA;
@@ -1319,7 +1327,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                 } while (0)
                 if (rows == 1) {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux, false);
-                    else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamC, true, false, block, true); else CK_LAUNCH_STREAM(StreamC, true, false, block, false); }
+                    else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamCH, true, false, block_h, true); else CK_LAUNCH_STREAM(StreamCH, true, false, block_h, false); }
                     else { if (alpha) CK_LAUNCH_STREAM(StreamC, false, false, block, true); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
                 } else {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux, false);

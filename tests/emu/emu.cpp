@@ -183,8 +183,9 @@ void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
     const bool aux = L->a.out_index || L->a.out_strand || (L->a.flags & ck::CK_FLAG_FWD_ONLY);
     if (aux) ck::canon_stream_wave_loop<C, true, true>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
     else if (L->a.out_hash) {
-        // the 16-wave, one-word build finishes XXH3 per record group (same condition as canon_stream_kernel)
-        constexpr bool GH = C::ROWS == 1 && C::RPW == 1 && C::GROUP == 16;
+        // the one-record-per-wave, one-word builds finish XXH3 per record group (same condition as canon_stream_kernel: groups of
+        // up to 16 records since round 4)
+        constexpr bool GH = C::ROWS == 1 && C::RPW == 1 && C::GROUP <= 16;
         if (L->alpha && C::ROWS == 1) ck::canon_stream_wave_loop<C, true, false, GH, C::ROWS == 1>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
         else ck::canon_stream_wave_loop<C, true, false, GH>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
     }
@@ -200,6 +201,8 @@ const StreamVariant kStream[] = {
     variant<ck::StreamCfg<4, 4, 1>>(), variant<ck::StreamCfg<8, 6, 1>>(), variant<ck::StreamCfg<4, 4>>(),
     // ROWS = 2: records of up to 2032 bases, two packed words per lane
     variant<ck::StreamCfg<16, 2, 1, 2>>(), variant<ck::StreamCfg<4, 2, 2, 2>>(), variant<ck::StreamCfg<8, 3, 1, 2>>(),
+    // the product's geometry of the builds with the fused XXH3 (round 4): 8 waves, one record each, two images
+    variant<ck::StreamCfg<8, 2, 1>>(),
 };
 }
 
@@ -233,7 +236,7 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     const uint64_t per_step = sv->group, steps = (n_records + per_step - 1) / per_step;
     const uint32_t cap = (uint32_t)(per_step * ((steps + G - 1) / G)) + 4;
     std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16 + ck::gh_lds_dw<16>()), list_f((size_t)G * cap), list_a((size_t)G * cap);
-    for (uint32_t tid = 0; tid < 4; ++tid) ck::group_hash_init(lds.data() + sv->lds_dw + 2 * 16 * ck::GH_STRIDE_DW, tid);
+    for (uint32_t tid = 0; tid < 4; ++tid) ck::group_hash_init(lds.data() + sv->lds_dw + 2 * sv->group * ck::GH_STRIDE_DW, tid);       // (canon_stream_kernel: behind the 2 x GROUP slots)
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[ck::FAST_LUT_DW];
     ck::fast_lut_init(lut, 0, 1);
