@@ -308,8 +308,10 @@ def main():
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         nvar = ", %g %% of the bases replaced by N" % (100 * args.n_frac) if args.n_frac > 0 else ""
         # the kernel chain the step really ran: which streaming build the batch's own mode picked, which table path
-        stream_build = "canon_stream_kernel<StreamCfg<16,2,1,%d>,%s,false,false,%s>" % (
-            2 if 1008 < L <= 2032 else 1, "true" if args.workload == "uniq" else "false", "true" if nvar and L <= 1008 else "false")
+        two_row = 1008 < L <= 2032
+        stream_build = "canon_stream_kernel<StreamCfg<%d,2,1,%d>,%s,false,false,%s>" % (
+            8 if args.workload == "uniq" and not two_row else 16,      # (the builds with the fused XXH3 run 8-wave workgroups)
+            2 if two_row else 1, "true" if args.workload == "uniq" else "false", "true" if nvar and L <= 1008 else "false")
         if args.workload == "canonicalize":
             metric = "canonicalize sequences/sec (%s x %d b synthetic FASTA payload)" % (
                 "10M" if N == 10_000_000 else "100M over 8 GPUs" if config5 else "%d per GPU" % N, L)
