@@ -177,7 +177,10 @@ CK_DEV uint32_t fast_pack(u32x4 v, uint32_t& miss)
         miss = sad_u8(perm(0u, CHK2_LO, sel), d[k], miss);
         u[k] = udot4(perm(0u, 0x02030100u, sel), 0x01041040u, 0u);
     }
-    return (((u[0] << 8 | u[1]) << 8 | u[2]) << 8) | u[3];
+    // the four code bytes into one word by v_perm (three instructions; as shifts and ORs the compiler emits six).  Through the
+    // builtin: a dot4 result read by inline assembly misses the wait states only the compiler's hazard recognizer inserts
+    // (wave_prims.h udot4; seen again in round 4 with v_lshl_or_b32 as the reader: stale registers)
+    return perm(perm(u[0], u[1], 0x0c0c0400u), perm(u[2], u[3], 0x0c0c0400u), 0x05040100u);
 }
 
 // 256-entry LDS table: packed byte (4 symbols, first in the top bits) -> its 4 ASCII bytes.  Replaces ~6 VALU

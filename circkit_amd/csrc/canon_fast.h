@@ -122,8 +122,18 @@ CK_DEV uint64_t fast_hash(const FastHashConst& hc, const uint32_t* lut, u32x4 ce
 //   entry from 16 slots are bank-conflict-free.
 constexpr uint32_t GH_STRIDE_DW = 144;
 constexpr uint32_t GH_CONST_DW = 48;            // per accumulator pair j: l0 l1 m0 m1 i0 i1 (6 x u64)
-template <int GROUP>
-constexpr uint32_t gh_lds_dw() { return 2 * GROUP * GH_STRIDE_DW + GH_CONST_DW; }
+constexpr uint32_t GH_SECRET_DW = 48;           // canon_pair.h only: XXH3's 192-byte secret behind the constants (the lanes' cell words are read from it)
+template <int GROUP, bool PAIR = false>
+constexpr uint32_t gh_lds_dw() { return 2 * GROUP * GH_STRIDE_DW + GH_CONST_DW + (PAIR ? GH_SECRET_DW : 0); }
+CK_DEV void group_hash_secret_init(uint32_t* sec, uint32_t tid)
+{
+    if (tid < GH_SECRET_DW) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) v = (v << 8) | XXH3_SECRET[4 * tid + i];
+        sec[tid] = v;
+    }
+}
 CK_DEV void group_hash_init(uint32_t* ghc, uint32_t tid)
 {
     if (tid < 4) {
@@ -152,7 +162,8 @@ CK_DEV void group_hash_put(uint32_t* slot, uint64_t k0, uint64_t k1, u32x4 cell,
     if (t == 0) { slot[128] = n; slot[129] = idx; slot[130] = 1; }
 }
 // merger: finishes the GROUP records of `slots` (records rec0 .. rec0 + GROUP - 1 of the batch)
-template <int GROUP>
+// NROWS: 16-lane rows of partial sums a producer leaves per record (4: one record per wave; 2: canon_pair.h, one per half-wave)
+template <int GROUP, int NROWS = 4>
 CK_DEV void group_hash_merge(const CanonArgs& a, const uint32_t* lut, const uint32_t* ghc, const uint32_t* slots, uint32_t rec0)
 {
     static_assert(GROUP <= 16, "one lane per (record, accumulator pair)");
@@ -163,7 +174,7 @@ CK_DEV void group_hash_merge(const CanonArgs& a, const uint32_t* lut, const uint
     const u32x4 cl = lds_load16(ghc + 12 * j), cm = lds_load16(ghc + 12 * j + 4), ci = lds_load16(ghc + 12 * j + 8);
     uint64_t a0 = ((uint64_t)ci.y << 32) | ci.x, a1 = ((uint64_t)ci.w << 32) | ci.z;
 #pragma unroll
-    for (uint32_t row = 0; row < 4; ++row) {
+    for (uint32_t row = 0; row < (uint32_t)NROWS; ++row) {
         const u32x4 v = lds_load16(s + row * 16 + j * 4);
         a0 += ((uint64_t)v.y << 32) | v.x;
         a1 += ((uint64_t)v.w << 32) | v.z;

@@ -13,6 +13,7 @@
 // 32 waves per CU; deeper rings with fewer waves measured slower (Measured).
 #pragma once
 #include "canon_fast.h"
+#include "canon_pair.h"
 
 namespace ck {
 
@@ -145,7 +146,11 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
 {
     static_assert(!ALPHA || !AUX, "index / strand outputs: the 4-bit records take the LDS tiers");
     static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
-    static_assert(!GH || (HASH && C::RPW == 1 && C::GROUP <= 16), "the group merger takes up to 16 records, one per wave");
+    static_assert(!GH || (HASH && !AUX && C::ROWS == 1 && C::GROUP <= 16), "the group merger takes up to 16 records of one packed word per 16 symbols");
+    // GH with two records per wave: canon_pair.h -- one record per half-wave, both at once
+    constexpr bool PAIR = GH && C::RPW == 2;
+    static_assert(!PAIR || !ALPHA, "the pair routine takes pure ACGT only (the ALPHA build keeps one record per wave)");
+    constexpr int SPW = PAIR ? 1 : C::RPW;            // vector-memory stores every wave is SURE to issue per iteration (pair: cell 0 of a finished record, or a deferral)
     constexpr int D = C::NBUF - 1;                    // groups in flight
     // the touches pay in the builds with the fused XXH3, which are bound by instruction issue (same box, 10M x 1 kb: bytes + hash
     // 4.16 -> 4.05 ms); the bytes-only build sits on the memory system and LOSES when its loads go out earlier (3.60 -> 4.00 ms
@@ -163,6 +168,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     FastHashConst hc{};
     if (HASH) hc = fast_hash_const();
     FastShape shape;
+    PairShape pshape;
     // does every record issue at least one store (bytes, hash, index or its deferral)?  The vmcnt arithmetic below counts
     // on it.  Not with the group merger on a hash-only batch: a record then leaves nothing but LDS writes.
     const bool stores = GH ? a.out_bytes != nullptr : (a.out_bytes || a.out_hash || a.out_index || a.out_strand);
@@ -239,10 +245,20 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
 #endif
         }
         const uint32_t* img = ring + img_dw;
-        uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + w) * GH_STRIDE_DW : nullptr;
-        if (GH) group_hash_invalidate(slot);
+        uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + C::RPW * w) * GH_STRIDE_DW : nullptr;
+        if constexpr (PAIR) {
+            // records ra, ra + 1 in the two halves of the wave
+            const uint32_t nA = (uint32_t)o1 - (uint32_t)o0, nB = (uint32_t)o2 - (uint32_t)o1;
+            const uint32_t elig = q[0].ok ? (fast_eligible(nA) ? 1u : 0u) | (fast_eligible(nB) ? 2u : 0u) : 0u;
+            uint32_t done = 0;
+            if (elig) done = pair_canon(a, lut, gh_const + GH_CONST_DW, pshape, img, q[0].base_lo, ra, o0, o1, (elig & 1) ? nA : 64u, (elig & 2) ? nB : 64u, elig, slot);
+            else { group_hash_invalidate(slot); group_hash_invalidate(slot + GH_STRIDE_DW); }
+            if (!(done & 1)) defer_record(a, blk_count, block, ra);
+            if (!(done & 2)) defer_record(a, blk_count, block, ra + 1);
+        }
+        if (GH && !PAIR) group_hash_invalidate(slot);
 #pragma unroll
-        for (int k = 0; k < C::RPW; ++k) {
+        for (int k = 0; k < (PAIR ? 0 : C::RPW); ++k) {
             const uint64_t off = k ? o1 : o0;                           // (o2 is loaded but unused when RPW == 1)
             const uint32_t n = (uint32_t)(k ? o2 : o1) - (uint32_t)off;
             const uint32_t rec = ra + k;
@@ -315,7 +331,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         // the previous group's hashes: its slots were complete at the barrier that ended the previous iteration
         if constexpr (GH) {
             if (it > 0 && w == ((it - 1) & (C::WPB - 1)))
-                group_hash_merge<(int)C::GROUP>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, (g - nblocks) * C::GROUP);
+                group_hash_merge<(int)C::GROUP, PAIR ? 2 : 4>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, (g - nblocks) * C::GROUP);
         }
         // the next group's DMAs (issued D-1 iterations ago) must have landed.  Younger vector-memory instructions:
         // the DMAs of the D-1 groups issued since (DPW each), and the stores of this and the D-1 previous iterations
@@ -327,8 +343,8 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         // (touches: one per iteration, issued right behind the iteration's DMAs -- D of them are younger than the DMAs waited
         // for, one at least while the next group is still one of the prologue's)
         if (!stores) { if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + PF>(); else vmem_wait<(D - 1) * C::DPW + D * PF>(); }
-        else if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + C::RPW + PF>();
-        else vmem_wait<(D - 1) * C::DPW + D * C::RPW + D * PF>();
+        else if (it + 1 < (uint32_t)D) vmem_wait<(D - 1) * C::DPW + SPW + PF>();
+        else vmem_wait<(D - 1) * C::DPW + D * SPW + D * PF>();
 #endif
         block_barrier();
 #pragma unroll
@@ -344,7 +360,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     if constexpr (GH) {
         if (it > 0 && w == ((it - 1) & (C::WPB - 1))) {             // the last group's hashes (behind the loop's final barrier)
             const uint32_t g_last = block + (it - 1) * nblocks;
-            group_hash_merge<(int)C::GROUP>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, g_last * C::GROUP);
+            group_hash_merge<(int)C::GROUP, PAIR ? 2 : 4>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, g_last * C::GROUP);
         }
     }
 }

@@ -242,6 +242,20 @@ using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
 #define CK_STREAM_WPB_HASH 8
 #endif
 using StreamCH = ck::StreamCfg<CK_STREAM_WPB_HASH, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
+// ... and, for batches of pure ACGT, take TWO records per wave, one per half-wave (canon_pair.h): the scalar side of an iteration
+// and the vector work that does not depend on the bytes are shared by two records.  CK_STREAM_WPB_PAIR waves, groups of twice as
+// many records; CK_PAIR_WPE waves per SIMD (the register budget the build is compiled for).  CK_STREAM_WPB_PAIR 0: no such build.
+#ifndef CK_STREAM_WPB_PAIR
+#define CK_STREAM_WPB_PAIR 8
+#endif
+#ifndef CK_PAIR_WPE
+#define CK_PAIR_WPE 6
+#endif
+#if CK_STREAM_WPB_PAIR
+using StreamCHP = ck::StreamCfg<CK_STREAM_WPB_PAIR, CK_STREAM_NBUF, 2, 1>;
+#else
+using StreamCHP = StreamCH;
+#endif
 // The build with every output (index / strand / forward-only) needs ~100 SGPRs: at 16 waves per workgroup only one
 // workgroup would fit a CU (measured: 5.1-5.7 ms instead of 3.4-4.0).  It keeps 4-wave workgroups (2 records per
 // wave), where SGPRs only cost a seventh wave per SIMD.
@@ -488,20 +502,22 @@ CK_MIXED_KERNEL(canon_mixed_nh_kernel, true, true, CK_MIXED_NM_VGPR)
 // ALPHA (ROWS = 1, no index / strand outputs): the build for batches with MODE_ALPHA -- records with N or '-' take the
 // 4-bit register routine inside the staged loop.  The builds without it answer for every other batch, MODE_ALPHA or not.
 template <class StreamC, bool HASH, bool AUX, bool PERSIST, bool ALPHA = false>
-__global__ __launch_bounds__(StreamC::WPB * 64, StreamC::WPB >= 8 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
+__global__ __launch_bounds__(StreamC::WPB * 64, (HASH && !AUX && !ALPHA && StreamC::ROWS == 1 && StreamC::RPW == 2) ? CK_PAIR_WPE : StreamC::WPB >= 8 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
                                                                                                              uint32_t host_mode, uint32_t nvb)
 {
     const uint32_t bm = batch_mode(mode, host_mode);
     if ((bm & 3) != (uint32_t)StreamC::ROWS) return;                             // the other build (or none) has this batch
     constexpr bool HAS_ALPHA_TWIN = StreamC::ROWS == 1 && !AUX;
     if (HAS_ALPHA_TWIN && ((bm & MODE_ALPHA) != 0) != ALPHA) return;
-    constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && StreamC::RPW == 1 && StreamC::GROUP <= 16;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<(int)StreamC::GROUP>() : 0)];
+    constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && (StreamC::RPW == 1 || !ALPHA) && StreamC::GROUP <= 16;
+    constexpr bool PAIR = GH && StreamC::RPW == 2;                                // canon_pair.h: two records per wave
+    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<(int)StreamC::GROUP, PAIR>() : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + ck::FAST_LUT_DW;
     uint32_t* gh = lds + StreamC::LDS_DW;
     ck::fast_lut_init(lut, threadIdx.x, StreamC::WPB * 64);
     if (GH) ck::group_hash_init(gh + 2 * StreamC::GROUP * ck::GH_STRIDE_DW, threadIdx.x);
+    if (PAIR) ck::group_hash_secret_init(gh + 2 * StreamC::GROUP * ck::GH_STRIDE_DW + ck::GH_CONST_DW, threadIdx.x);
     if (!PERSIST) {
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
@@ -1310,7 +1326,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const uint32_t seen = *c->h_mode;
         const uint32_t expect = host_mode ? host_mode & 3 : ((seen & 3) ? seen & 3 : 1u);
         const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
-        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64), block_h(StreamCH::WPB * 64);
+        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64), block_h(StreamCH::WPB * 64), block_hp(StreamCHP::WPB * 64);
         // (rows, alphabet) builds: ROWS = 1 lean, ROWS = 1 with the 4-bit routine, ROWS = 2.  The host's answer launches
         // exactly one; a device-side decision launches all three, full-size where the previous batch's mode says it will run
         const uint32_t expect_alpha = host_mode ? host_mode & MODE_ALPHA : seen & MODE_ALPHA;
@@ -1327,7 +1343,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                 } while (0)
                 if (rows == 1) {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux, false);
-                    else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamCH, true, false, block_h, true); else CK_LAUNCH_STREAM(StreamCH, true, false, block_h, false); }
+                    else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamCH, true, false, block_h, true); else CK_LAUNCH_STREAM(StreamCHP, true, false, block_hp, false); }
                     else { if (alpha) CK_LAUNCH_STREAM(StreamC, false, false, block, true); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
                 } else {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux, false);

@@ -152,6 +152,66 @@ CK_DEV void wave_min2_u32(uint32_t x, uint32_t y, uint32_t& mx, uint32_t& my)
     mx = readlane(x, 63);
     my = readlane(y, 63);
 }
+// The same for the two HALVES of the wave apart (lanes 0..31 / 32..63: canon_pair.h runs one record in each): the row steps, then
+// rows 1 and 3 take the minimum with lane 15 of rows 0 and 2 -- lanes 31 and 63 hold their half's minimum.
+CK_DEV void half_min2_u32(uint32_t x, uint32_t y, uint32_t& xa, uint32_t& xb, uint32_t& ya, uint32_t& yb)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x), "+v"(y));
+    xa = readlane(x, 31); xb = readlane(x, 63);
+    ya = readlane(y, 31); yb = readlane(y, 63);
+}
+// lo = x of lane t & 31, hi = x of lane 32 + (t & 31): the lower / upper half of the wave shown to both halves (gfx950:
+// v_permlane32_swap_b32 exchanges the upper 32 lanes of one register with the lower 32 of another -- here the same value twice)
+CK_DEV void half_bcast(uint32_t x, uint32_t& lo, uint32_t& hi)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    lo = r[0]; hi = r[1];
+}
+// ... and with the result in every lane of the half instead of in scalars: rows 1 and 3 hold it after the row_bcast step, and
+// v_permlane16_swap_b32 (gfx950: swaps the odd rows of one register with the even rows of another) of the value with itself
+// leaves rows 1, 1, 3, 3 in its second result.
+CK_DEV void half_min2_bcast_u32(uint32_t x, uint32_t y, uint32_t& mx, uint32_t& my)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_min_u32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(x), "+v"(y));
+    mx = __builtin_amdgcn_permlane16_swap(x, x, false, false)[1];
+    my = __builtin_amdgcn_permlane16_swap(y, y, false, false)[1];
+}
+// a wave-uniform 64-bit mask as a per-lane predicate (no instruction: the mask is used as the exec / select operand)
+CK_DEV bool lane_pred(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 // low 32 bits of (hi:lo) >> s, s in 0..63
 CK_DEV uint32_t lshr64(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s); }
 CK_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }   // v_bfi_b32
@@ -171,6 +231,9 @@ CK_DEV uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
 {
     return sh ? __builtin_amdgcn_alignbit(hi, lo, 32u - sh) : hi;   // v_alignbit_b32: ({hi,lo} >> n)[31:0]
 }
+// low 32 bits of (hi:lo) >> (s & 31): ONE full-rate instruction (v_alignbit_b32; the 64-bit shift behind lshr64() issues at half
+// rate and wants its operands in a register pair -- tools/microbench/valu_rate.hip)
+CK_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
 CK_DEV uint32_t bitrev(uint32_t v) { return __builtin_bitreverse32(v); }
 CK_DEV int ffs64(uint64_t v) { return __builtin_ctzll(v); }   // v != 0
 CK_DEV int ffs32(uint32_t v) { return __builtin_ctz(v); }     // v != 0

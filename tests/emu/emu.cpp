@@ -185,9 +185,10 @@ void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
     else if (L->a.out_hash) {
         // the one-record-per-wave, one-word builds finish XXH3 per record group (same condition as canon_stream_kernel: groups of
         // up to 16 records since round 4)
-        constexpr bool GH = C::ROWS == 1 && C::RPW == 1 && C::GROUP <= 16;
+        // ...; two records per wave without the 4-bit routine: canon_pair.h, one record per half-wave)
+        constexpr bool GH = C::ROWS == 1 && C::RPW == 1 && C::GROUP <= 16, GHP = C::ROWS == 1 && C::GROUP <= 16;
         if (L->alpha && C::ROWS == 1) ck::canon_stream_wave_loop<C, true, false, GH, C::ROWS == 1>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
-        else ck::canon_stream_wave_loop<C, true, false, GH>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
+        else ck::canon_stream_wave_loop<C, true, false, GHP>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
     }
     else if (L->alpha && C::ROWS == 1) ck::canon_stream_wave_loop<C, false, false, false, C::ROWS == 1>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
     else ck::canon_stream_wave_loop<C, false, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
@@ -203,6 +204,8 @@ const StreamVariant kStream[] = {
     variant<ck::StreamCfg<16, 2, 1, 2>>(), variant<ck::StreamCfg<4, 2, 2, 2>>(), variant<ck::StreamCfg<8, 3, 1, 2>>(),
     // the product's geometry of the builds with the fused XXH3 (round 4): 8 waves, one record each, two images
     variant<ck::StreamCfg<8, 2, 1>>(),
+    // ... and of the pair build: 4 waves, two records each (one per half-wave), groups of 8
+    variant<ck::StreamCfg<4, 2, 2>>(), variant<ck::StreamCfg<8, 2, 2>>(),
 };
 }
 
@@ -235,7 +238,8 @@ extern "C" int emu_canonicalize_batch(const uint8_t* bytes, const uint64_t* offs
     const bool all_records = staged == 0;
     const uint64_t per_step = sv->group, steps = (n_records + per_step - 1) / per_step;
     const uint32_t cap = (uint32_t)(per_step * ((steps + G - 1) / G)) + 4;
-    std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16 + ck::gh_lds_dw<16>()), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    std::vector<uint32_t> lds((sv->lds_dw > slice_dw * 4 ? sv->lds_dw : slice_dw * 4) + 1024 + 16 + ck::gh_lds_dw<16, true>()), list_f((size_t)G * cap), list_a((size_t)G * cap);
+    for (uint32_t tid = 0; tid < ck::GH_SECRET_DW; ++tid) ck::group_hash_secret_init(lds.data() + sv->lds_dw + 2 * sv->group * ck::GH_STRIDE_DW + ck::GH_CONST_DW, tid);
     for (uint32_t tid = 0; tid < 4; ++tid) ck::group_hash_init(lds.data() + sv->lds_dw + 2 * sv->group * ck::GH_STRIDE_DW, tid);       // (canon_stream_kernel: behind the 2 x GROUP slots)
     std::vector<uint32_t> cnt_f(G, 0), cnt_a(G, 0);
     uint32_t status = 0, lut[ck::FAST_LUT_DW];

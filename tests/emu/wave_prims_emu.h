@@ -78,6 +78,28 @@ CK_DEV void wave_min2_u32(uint32_t x, uint32_t y, uint32_t& mx, uint32_t& my)
     mx = wave_min_u32(x);
     my = wave_min_u32(y);
 }
+CK_DEV void half_min2_u32(uint32_t x, uint32_t y, uint32_t& xa, uint32_t& xb, uint32_t& ya, uint32_t& yb)
+{
+    uint64_t ax[64], ay[64];
+    emu::gather(x, ax); emu::gather(y, ay);
+    xa = xb = ya = yb = ~0u;
+    for (int i = 0; i < 32; ++i) {
+        xa = (uint32_t)ax[i] < xa ? (uint32_t)ax[i] : xa; xb = (uint32_t)ax[32 + i] < xb ? (uint32_t)ax[32 + i] : xb;
+        ya = (uint32_t)ay[i] < ya ? (uint32_t)ay[i] : ya; yb = (uint32_t)ay[32 + i] < yb ? (uint32_t)ay[32 + i] : yb;
+    }
+}
+CK_DEV void half_bcast(uint32_t x, uint32_t& lo, uint32_t& hi)
+{
+    uint64_t all[64]; emu::gather(x, all);
+    lo = (uint32_t)all[lane_id() & 31]; hi = (uint32_t)all[32 + (lane_id() & 31)];
+}
+CK_DEV void half_min2_bcast_u32(uint32_t x, uint32_t y, uint32_t& mx, uint32_t& my)
+{
+    uint32_t xa, xb, ya, yb;
+    half_min2_u32(x, y, xa, xb, ya, yb);
+    mx = lane_id() < 32 ? xa : xb; my = lane_id() < 32 ? ya : yb;
+}
+CK_DEV bool lane_pred(uint64_t m) { return ((m >> lane_id()) & 1) != 0; }
 CK_DEV uint32_t row_min16_u32(uint32_t v)
 {
     uint64_t all[64]; emu::gather(v, all);
@@ -105,6 +127,7 @@ CK_DEV uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh)
 {
     return sh ? (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (32u - sh)) : hi;
 }
+CK_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (s & 31)); }
 CK_DEV uint32_t bitrev(uint32_t v)
 {
     uint32_t r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
