@@ -251,6 +251,16 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
             const uint32_t nA = (uint32_t)o1 - (uint32_t)o0, nB = (uint32_t)o2 - (uint32_t)o1;
             const uint32_t elig = q[0].ok ? (fast_eligible(nA) ? 1u : 0u) | (fast_eligible(nB) ? 2u : 0u) : 0u;
             uint32_t done = 0;
+#ifdef CK_DEBUG_POISON
+            if (elig) {     // the chunks pair_canon is about to pack (same addressing)
+                const uint32_t hbp = t >> 5, up = t & 31, relp = (uint32_t)o0 - q[0].base_lo + (hbp ? (uint32_t)(o1 - o0) : 0u);
+                const uint32_t nchp = ((relp & 15) + (hbp ? nB : nA) + 15) >> 4;
+                const bool el = ((elig >> hbp) & 1) != 0;
+                const uint32_t* cpp = img + 4 * ((relp >> 4) + 2 * up);
+                stream_poison_check(a, lds_load16(cpp), ballot(el && 2 * up < nchp));
+                stream_poison_check(a, lds_load16(cpp + 4), ballot(el && 2 * up + 1 < nchp));
+            }
+#endif
             if (elig) done = pair_canon(a, lut, gh_const + GH_CONST_DW, pshape, img, q[0].base_lo, ra, o0, o1, (elig & 1) ? nA : 64u, (elig & 2) ? nB : 64u, elig, slot);
             else { group_hash_invalidate(slot); group_hash_invalidate(slot + GH_STRIDE_DW); }
             if (!(done & 1)) defer_record(a, blk_count, block, ra);

@@ -780,3 +780,45 @@ def test_tapered_segments_tile_the_batch():
     # no taper = the plain mapping
     assert lib.emu_seg_cover(1000, 10, 100, 0, 0) == 10
     assert lib.emu_seg_cover(1001, 10, 100, 0, 0) == -1
+
+
+@pytest.mark.parametrize("staged", [14, 15])
+@pytest.mark.parametrize("hash_only", [False, True])
+def test_pair_build_two_records_per_wave(staged, hash_only):
+    """canon_pair.h (the fused-XXH3 streaming build for pure-ACGT batches): record A in lanes 0..31, record B in lanes 32..63 of one
+    wave.  The halves must not see each other: every combination of a record the routine takes with a partner it does not
+    (too short, too long, an N, a gap, a periodic record, a tied 8-symbol minimum, a reverse-complement palindrome), lengths on
+    and off the 16-symbol grid in either half (the periodic extension's r == 0 / r != 0 forms), the limits 48 and 1008, XXH3's
+    short-input classes (<= 240: left to the xxh3 pass, through a view when no bytes are written), every alignment of the
+    record in its first chunk."""
+    import random
+    rng = random.Random(4100 + staged)
+    R = lambda n, al=b"ACGT": seqsets.rand_seq(rng, n, al)
+    pal = R(40)
+    pal = pal + bytes(O.revcomp(pal))                                                 # its own reverse complement
+    odd = [b"", R(7), R(47), R(1009), R(1500), R(3000), R(500)[:250] + b"N" + R(249), R(300) + b"-" + R(300), b"ACGT" * 200, b"A" * 777,
+           (R(31) * 40)[:900], pal * 8, b"T" * 48, R(100, b"AC"), bytes(range(0x30, 0x7B)) * 5]
+    good = [R(n) for n in (48, 49, 63, 64, 65, 240, 241, 255, 256, 257, 511, 512, 513, 527, 528, 529, 992, 1000, 1007, 1008)]
+    seqs = []
+    for g in good:
+        o = rng.choice(odd)
+        seqs += [g, o] if rng.random() < 0.5 else [o, g]
+    for _ in range(60):
+        seqs += [R(rng.randint(48, 1008)), R(rng.randint(48, 1008))]
+    seqs += [R(1000) for _ in range(40)]                                               # (equal lengths: the lane constants are reused)
+    seqs += [R(rng.choice([48, 64, 1008])) for _ in range(16)]
+    data, offs = seqsets.pack(seqs)
+    for base_shift in (0, 5):
+        out, _, _, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=True, want_aux=False, staged=staged, slice_dw=4096, n_waves=8,
+                                                            hash_only=hash_only, base_shift=base_shift)
+        assert status == 0 and ndef == 0
+        n_pair = sum(1 for s in seqs[:len(seqs) // (8 if staged == 14 else 16) * (8 if staged == 14 else 16)] if 48 <= len(s) <= 1008 and set(s) <= set(b"ACGT"))
+        # (not all of them: the periodic and tied ones are refused, a group with a 3 kb record in it is not staged at all)
+        assert emu.last_fast_count >= n_pair * 3 // 4
+        for i, s in enumerate(seqs):
+            c = seqsets.expected(O, s)[0]
+            if not hash_only:
+                assert out[int(offs[i]):int(offs[i + 1])].tobytes() == c, (i, len(s), s[:60])
+            assert int(h[i]) == O.xxh3_64(c), (i, len(s), s[:60])
+        if hash_only:
+            assert (out == 0x3F).all()
