@@ -309,9 +309,11 @@ def main():
         nvar = ", %g %% of the bases replaced by N" % (100 * args.n_frac) if args.n_frac > 0 else ""
         # the kernel chain the step really ran: which streaming build the batch's own mode picked, which table path
         two_row = 1008 < L <= 2032
-        stream_build = "canon_stream_kernel<StreamCfg<%d,2,1,%d>,%s,false,false,%s>" % (
-            8 if args.workload == "uniq" and not two_row else 16,      # (the builds with the fused XXH3 run 8-wave workgroups)
-            2 if two_row else 1, "true" if args.workload == "uniq" else "false", "true" if nvar and L <= 1008 else "false")
+        hashb = args.workload == "uniq"
+        pair = hashb and not two_row and not nvar       # the builds with the fused XXH3: 8-wave workgroups; pure ACGT: two records per wave (canon_pair.h)
+        stream_build = "canon_stream_kernel<StreamCfg<%d,2,%d,%d>,%s,false,false,%s>" % (
+            8 if hashb and not two_row else 16, 2 if pair else 1,
+            2 if two_row else 1, "true" if hashb else "false", "true" if nvar and L <= 1008 else "false")
         if args.workload == "canonicalize":
             metric = "canonicalize sequences/sec (%s x %d b synthetic FASTA payload)" % (
                 "10M" if N == 10_000_000 else "100M over 8 GPUs" if config5 else "%d per GPU" % N, L)

@@ -178,8 +178,8 @@ CK_DEV uint32_t pair_canon(const CanonArgs& a, const uint32_t* lut, const uint32
     {   // periodic extension (pair_shape)
         const uint32_t* Se = S + sh.e0;
         const uint32_t x0 = Se[0], x1 = Se[1], x2 = Se[2];
-        W0 = bfi(sh.m0, W0, alignbit(x0, x1, sh.sft));
-        W1 = bfi(sh.m1, W1, alignbit(x1, x2, sh.sft));
+        W0 = bfi_v(sh.m0, W0, alignbit(x0, x1, sh.sft));
+        W1 = bfi_v(sh.m1, W1, alignbit(x1, x2, sh.sft));
     }
     wave_sync();
     S[2 * u] = W0; S[2 * u + 1] = W1;

@@ -978,8 +978,11 @@ __global__ __launch_bounds__(1024) void uniq_bkt_basescan_kernel(const uint32_t*
 }
 // rows[base[b] + ...] = {hash, local index}; a workgroup's keys of bucket b start at base[b] + its prefix in the count matrix
 __global__ __launch_bounds__(1024) void uniq_bkt_scatter_kernel(const uint64_t* __restrict__ hash, uint64_t n, uint64_t per, uint32_t log2b,
-                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ base, uint64_t* rows)
+                                                                const uint32_t* __restrict__ counts, const uint32_t* __restrict__ base, uint64_t* rows,
+                                                                uint64_t* first_seen, uint64_t base_index)
 {
+    // (every record starts out as its own first occurrence, written here in record order -- coalesced; the resolve kernel then
+    // only has scattered answers for the records that are NOT: half the batch in BASELINE config 3, next to none in real inputs)
     extern __shared__ uint32_t bkt_lds[];
     const uint32_t B = 1u << log2b;
     for (uint32_t b = threadIdx.x; b < B; b += 1024) bkt_lds[b] = base[b] + counts[(uint64_t)blockIdx.x * B + b];
@@ -996,12 +999,14 @@ __global__ __launch_bounds__(1024) void uniq_bkt_scatter_kernel(const uint64_t* 
         for (int u = 0; u < U; ++u) {
             const uint32_t pos = atomicAdd(&bkt_lds[bkt_of(h[u], log2b)], 1u);
             *reinterpret_cast<v2*>(rows + 2 * (uint64_t)pos) = v2{ h[u], i + u * 1024 };
+            first_seen[i + u * 1024] = base_index + i + u * 1024;
         }
     }
     for (; i < i1; i += 1024) {
         const uint64_t h = hash[i];
         const uint32_t pos = atomicAdd(&bkt_lds[bkt_of(h, log2b)], 1u);
         *reinterpret_cast<v2*>(rows + 2 * (uint64_t)pos) = v2{ h, i };
+        first_seen[i] = base_index + i;
     }
 }
 // one workgroup per bucket: smallest local index per key in an LDS table, then every row's answer to its record's place
@@ -1053,7 +1058,7 @@ __global__ __launch_bounds__(BKT_RESOLVE_T) void uniq_bkt_resolve_kernel(const u
             while (keys[s] != h) s = (s + 1) & (BKT_SLOTS - 1);
             m = idx[s];
         }
-        first_seen[ik[k]] = base_index + m;             // (the one scattered store per record; keep[] follows from it, coalesced)
+        if (m != ik[k]) first_seen[ik[k]] = base_index + m;     // (the one scattered store, for records that repeat an earlier one; keep[] follows, coalesced)
     }
 }
 // keep[i] = 1 iff record i is the first with its hash
@@ -2220,7 +2225,7 @@ int circkit_uniq_resolve_device(circkit_ctx* c, const uint64_t* d_hash, uint64_t
         hipLaunchKernelGGL(uniq_bkt_count_kernel, dim3(BKT_NW), dim3(1024), B * 4, c->stream, d_hash, n, per, log2b, counts, flag, c->d_counters + 4);
         hipLaunchKernelGGL(uniq_bkt_colscan_kernel, dim3(B / 64), dim3(1024), 0, c->stream, counts, B, tot);
         hipLaunchKernelGGL(uniq_bkt_basescan_kernel, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)tot, B, base);
-        hipLaunchKernelGGL(uniq_bkt_scatter_kernel, dim3(BKT_NW), dim3(1024), B * 4, c->stream, d_hash, n, per, log2b, (const uint32_t*)counts, (const uint32_t*)base, rows);
+        hipLaunchKernelGGL(uniq_bkt_scatter_kernel, dim3(BKT_NW), dim3(1024), B * 4, c->stream, d_hash, n, per, log2b, (const uint32_t*)counts, (const uint32_t*)base, rows, d_first_seen, base_index);
         hipLaunchKernelGGL(uniq_bkt_resolve_kernel, dim3(B), dim3(BKT_RESOLVE_T), 0, c->stream, (const uint64_t*)rows, (const uint32_t*)base, base_index, d_first_seen, d_keep, flag);
         if (d_keep) hipLaunchKernelGGL(uniq_keep_kernel, dim3(N_CU * CK_UNIQ_BPC), dim3(256), 0, c->stream, (const uint64_t*)d_first_seen, n, base_index, d_keep, (const uint32_t*)flag);
         // the fallback (a bucket beyond BKT_MAX keys): the HBM table over the whole shard; three launches that return at once otherwise

@@ -215,6 +215,14 @@ CK_DEV bool lane_pred(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m
 // low 32 bits of (hi:lo) >> s, s in 0..63
 CK_DEV uint32_t lshr64(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s); }
 CK_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }   // v_bfi_b32
+// the same as ONE instruction whatever the compiler makes of the expression (with a mask that is a loop-invariant register it
+// emits not / and / and / or)
+CK_DEV uint32_t bfi_v(uint32_t mask, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
 CK_DEV uint64_t wave_sum_u64(uint64_t v)
 {
 #pragma unroll

@@ -109,6 +109,7 @@ CK_DEV uint32_t row_min16_u32(uint32_t v)
 }
 CK_DEV uint32_t lshr64(uint32_t hi, uint32_t lo, uint32_t s) { return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> s); }
 CK_DEV uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
+CK_DEV uint32_t bfi_v(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
 CK_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
 {
     uint64_t src = ((uint64_t)s0 << 32) | s1;
