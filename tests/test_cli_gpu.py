@@ -284,3 +284,34 @@ def test_clap_forms_canonicalize(args):
     r = run(*args, fixture("multiple_sequences", "in.fasta"))
     assert r.returncode == 0 and r.stderr == b""
     assert id_seq_map(r.stdout) == id_seq_map(open(fixture("multiple_sequences", "out.fasta"), "rb").read())
+
+
+def test_supervisor_and_worker(tmp_path):
+    """The GPU arms run in a worker process; the process the caller started is a supervisor that leaves with the worker's status
+    as soon as the worker reports that all output is written and closed (the worker's 768 MB of pinned buffers, its mapping of
+    the input and its GPU context are then taken apart in the background: 0.3 s of a 5 GB run's wall time).  Same bytes and
+    same exit status with CIRCKIT_CLI_NO_SUPERVISOR=1 (one process); an error exit of the worker is the supervisor's; a
+    consumer on a pipe gets all of the output and its end of file; SIGTERM to the supervisor ends the worker."""
+    import signal
+    import time
+    src = fixture("multiple_sequences", "in.fasta")
+    out_a, out_b = tmp_path / "a.fasta", tmp_path / "b.fasta"
+    assert run("canonicalize", src, "-o", str(out_a)).returncode == 0
+    r = subprocess.run([BIN, "canonicalize", src, "-o", str(out_b)], capture_output=True, timeout=120, env=dict(os.environ, CIRCKIT_CLI_NO_SUPERVISOR="1"))
+    assert r.returncode == 0 and out_a.read_bytes() == out_b.read_bytes() and out_a.stat().st_size > 0
+    for env in (dict(os.environ), dict(os.environ, CIRCKIT_CLI_NO_SUPERVISOR="1")):
+        bad = tmp_path / "not.fasta"
+        bad.write_bytes(b"this is not FASTA\n")
+        r = subprocess.run([BIN, "uniq", str(bad)], capture_output=True, timeout=120, env=env)
+        assert r.returncode == 1 and r.stderr                                            # (the worker's die())
+    # a pipe consumer: complete output, and `cat` ends (the worker closes its stdout before it reports)
+    p = subprocess.run("%s canonicalize %s | cat" % (BIN, src), shell=True, capture_output=True, timeout=60)
+    assert p.returncode == 0 and p.stdout == out_a.read_bytes()
+    # signals are passed on: a run reading an endless stdin is ended by SIGTERM to the process we started
+    proc = subprocess.Popen([BIN, "canonicalize"], stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    proc.stdin.write(b">r\nACGTACGTAC\n")
+    proc.stdin.flush()
+    time.sleep(1.0)
+    proc.send_signal(signal.SIGTERM)
+    assert proc.wait(timeout=30) in (-signal.SIGTERM, 128 + signal.SIGTERM)
+    proc.stdin.close()
