@@ -51,7 +51,15 @@ CK_DEV uint32_t lean_mask_window(const uint16_t* Mk, int32_t s)
 // the 16 symbols at LDS symbol index s (first in the top bits); E[-1] .. E[nW] are valid
 // (a 64-bit shift, not funnel(): with a lane-varying shift the compiler turns funnel()'s "sh ? alignbit : hi" into an exec-mask
 // region around the second LDS read and a v_mul_lo_u32 by 30 for the shift amount -- a quarter-rate instruction per window)
-CK_DEV uint32_t lean_window(const uint32_t* E, int32_t s) { return lshr64(E[s >> 4], E[(s >> 4) + 1], 32 - ((uint32_t)s & 15) * 2); }
+// (end of round 4: not the 64-bit shift either -- v_lshrrev_b64 issues at half rate and wants a register pair, tools/microbench/
+// valu_rate.hip.  With q = s + 15 the window is the words E[(q >> 4) - 1], E[q >> 4] shifted right by 30 - 2 (q & 15) = 0..30 bits:
+// ONE v_alignbit_b32, whose five shift bits are those of (2q) ^ 30 (canon_pair.h pair_window).  s >= 0; E[-1] is valid.)
+CK_DEV uint32_t lean_window(const uint32_t* E, int32_t s)
+{
+    const uint32_t q = (uint32_t)s + 15;
+    const uint32_t* w = E - 1 + (q >> 4);
+    return alignbit(w[0], w[1], (q << 1) ^ 30u);
+}
 
 // Strand from aligned chunks; returns false when a chunk holds a byte outside the alphabet (the first and last chunk also
 // hold the neighbours' bytes: a stranger there sends the record to stage A for nothing, which is harmless).

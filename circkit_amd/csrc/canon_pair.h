@@ -152,6 +152,10 @@ CK_DEV uint32_t pair_min32(uint32_t a, uint32_t b, uint32_t c, const PairShape& 
 // the motions.  slot0 = record A's XXH3 slot, record B's follows (canon_fast.h: [0,64) row sums, [64,128) the winning strand,
 // [128..130] n, rotation, valid); every call leaves both slots' valid words set or cleared.  Returns bit h = record h is done;
 // the others are the caller's to defer.
+// HASHING = false (the bytes-only pair build): no XXH3, and `slot0` is the wave's scratch for the two strand copies, PAIR_SCRATCH_DW
+// dwords per record (four in front of the copy: its words -3 .. -1 are read, never used).
+constexpr uint32_t PAIR_SCRATCH_DW = 72;
+template <bool HASHING = true>
 CK_DEV uint32_t pair_canon(const CanonArgs& a, const uint32_t* lut, const uint32_t* sec, PairShape& sh, const uint32_t* img, uint32_t base_lo,
                            uint32_t rec0, uint64_t offA, uint64_t offB, uint32_t nA, uint32_t nB, uint32_t elig, uint32_t* slot0)
 {
@@ -171,8 +175,8 @@ CK_DEV uint32_t pair_canon(const CanonArgs& a, const uint32_t* lut, const uint32
     // the record starts a16 bytes into its first chunk: removed on the packed words
     const uint32_t sh2 = 32 - 2 * a16;
     uint32_t W0 = lshr64(P0, P1, sh2), W1 = lshr64(P1, wave_shl1(P0), sh2);
-    uint32_t* slot = slot0 + (hb ? GH_STRIDE_DW : 0u);
-    uint32_t* S = slot + 64;
+    uint32_t* slot = slot0 + (hb ? (HASHING ? GH_STRIDE_DW : PAIR_SCRATCH_DW) : 0u);
+    uint32_t* S = slot + (HASHING ? 64 : 4);
     S[2 * u] = W0; S[2 * u + 1] = W1;
     wave_sync();
     {   // periodic extension (pair_shape)
@@ -209,11 +213,11 @@ CK_DEV uint32_t pair_canon(const CanonArgs& a, const uint32_t* lut, const uint32
     const uint32_t iA = (ok & 1) ? loc.posA : 0u, iB = (ok & 2) ? loc.posB : 0u;                 // (a failed half: in range, unused)
     const uint32_t idx = iA + (hb ? iB - iA : 0u);
     const uint64_t okm = ((ok & 1) ? 0xFFFFFFFFull : 0ull) | ((ok & 2) ? 0xFFFFFFFF00000000ull : 0ull);
-    const bool hashing = a.out_hash != nullptr;
+    const bool hashing = HASHING && a.out_hash != nullptr;
     // the winning strand into the slot: the rotation fetch below and the merger's last stripe read it
     wave_sync();
     S[2 * u] = fwd ? W0 : C0; S[2 * u + 1] = fwd ? W1 : C1;
-    if (u == 0) { slot[128] = n; slot[129] = idx; slot[130] = lane_pred(okm) && hashing && n > 240 ? 1u : 0u; }   // (XXH3's long-input path; shorter: the xxh3 pass)
+    if (HASHING && u == 0) { slot[128] = n; slot[129] = idx; slot[130] = lane_pred(okm) && hashing && n > 240 ? 1u : 0u; }   // (XXH3's long-input path; shorter: the xxh3 pass)
     wave_sync();
     uint64_t c0 = 0, c1 = 0;
     // secret words of the lane's two XXH3 cells (stripe (u >> 2) + 8k, pair u & 3): 16 bytes at offset 8 * stripe + 16 * pair of the

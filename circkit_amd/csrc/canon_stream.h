@@ -30,6 +30,9 @@ namespace ck {
 #ifndef CK_STREAM_TOUCH
 #define CK_STREAM_TOUCH 1
 #endif
+#ifndef CK_STREAM_PAIR_BYTES
+#define CK_STREAM_PAIR_BYTES 0     // EXPERIMENT: two records per wave (canon_pair.h) in the bytes-only build too
+#endif
 template <int WPB_, int NBUF_, int RPW_ = 2, int ROWS_ = 1>
 struct StreamCfg {
     static constexpr int WPB = WPB_, RPW = RPW_, NBUF = NBUF_;
@@ -148,7 +151,9 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
     static_assert(!GH || (HASH && !AUX && C::ROWS == 1 && C::GROUP <= 16), "the group merger takes up to 16 records of one packed word per 16 symbols");
     // GH with two records per wave: canon_pair.h -- one record per half-wave, both at once
-    constexpr bool PAIR = GH && C::RPW == 2;
+    // ... and, CK_STREAM_PAIR_BYTES, the bytes-only build of such a geometry as well (gh = PAIR_SCRATCH_DW dwords per record then)
+    constexpr bool PAIR_B = CK_STREAM_PAIR_BYTES && !HASH && !AUX && !ALPHA && C::ROWS == 1 && C::RPW == 2;
+    constexpr bool PAIR = (GH && C::RPW == 2) || PAIR_B;
     static_assert(!PAIR || !ALPHA, "the pair routine takes pure ACGT only (the ALPHA build keeps one record per wave)");
     constexpr int SPW = PAIR ? 1 : C::RPW;            // vector-memory stores every wave is SURE to issue per iteration (pair: cell 0 of a finished record, or a deferral)
     constexpr int D = C::NBUF - 1;                    // groups in flight
@@ -245,7 +250,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
 #endif
         }
         const uint32_t* img = ring + img_dw;
-        uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + C::RPW * w) * GH_STRIDE_DW : nullptr;
+        uint32_t* slot = GH ? gh + ((it & 1) * C::GROUP + C::RPW * w) * GH_STRIDE_DW : PAIR_B ? gh + C::RPW * w * PAIR_SCRATCH_DW : nullptr;
         if constexpr (PAIR) {
             // records ra, ra + 1 in the two halves of the wave
             const uint32_t nA = (uint32_t)o1 - (uint32_t)o0, nB = (uint32_t)o2 - (uint32_t)o1;
@@ -261,8 +266,8 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 stream_poison_check(a, lds_load16(cpp + 4), ballot(el && 2 * up + 1 < nchp));
             }
 #endif
-            if (elig) done = pair_canon(a, lut, gh_const + GH_CONST_DW, pshape, img, q[0].base_lo, ra, o0, o1, (elig & 1) ? nA : 64u, (elig & 2) ? nB : 64u, elig, slot);
-            else { group_hash_invalidate(slot); group_hash_invalidate(slot + GH_STRIDE_DW); }
+            if (elig) done = pair_canon<!PAIR_B>(a, lut, PAIR_B ? nullptr : gh_const + GH_CONST_DW, pshape, img, q[0].base_lo, ra, o0, o1, (elig & 1) ? nA : 64u, (elig & 2) ? nB : 64u, elig, slot);
+            else if (!PAIR_B) { group_hash_invalidate(slot); group_hash_invalidate(slot + GH_STRIDE_DW); }
             if (!(done & 1)) defer_record(a, blk_count, block, ra);
             if (!(done & 2)) defer_record(a, blk_count, block, ra + 1);
         }

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(StreamC::WPB * 64, (HASH && !AUX && !ALPHA && Strea
     if (HAS_ALPHA_TWIN && ((bm & MODE_ALPHA) != 0) != ALPHA) return;
     constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && (StreamC::RPW == 1 || !ALPHA) && StreamC::GROUP <= 16;
     constexpr bool PAIR = GH && StreamC::RPW == 2;                                // canon_pair.h: two records per wave
-    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<(int)StreamC::GROUP, PAIR>() : 0)];
+    constexpr bool PAIR_B = CK_STREAM_PAIR_BYTES && !HASH && !AUX && !ALPHA && StreamC::ROWS == 1 && StreamC::RPW == 2;    // (experiment: bytes only)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<(int)StreamC::GROUP, PAIR>() : PAIR_B ? StreamC::GROUP * ck::PAIR_SCRATCH_DW : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + ck::FAST_LUT_DW;
     uint32_t* gh = lds + StreamC::LDS_DW;
@@ -1349,7 +1350,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                 if (rows == 1) {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux, false);
                     else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamCH, true, false, block_h, true); else CK_LAUNCH_STREAM(StreamCHP, true, false, block_hp, false); }
-                    else { if (alpha) CK_LAUNCH_STREAM(StreamC, false, false, block, true); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
+                    else { if (alpha) CK_LAUNCH_STREAM(StreamC, false, false, block, true); else if (CK_STREAM_PAIR_BYTES) CK_LAUNCH_STREAM(StreamCHP, false, false, block_hp, false); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
                 } else {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux, false);
                     else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block, false);
