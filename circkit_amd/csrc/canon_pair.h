@@ -14,6 +14,9 @@
 // by exactly one position, or whose strands tie, goes to the deferral list.
 #pragma once
 #include "canon_fast.h"
+#ifndef CK_PAIR_SCALAR_VALID
+#define CK_PAIR_SCALAR_VALID 0
+#endif
 
 namespace ck {
 
@@ -165,12 +168,23 @@ CK_DEV uint32_t pair_canon(const CanonArgs& a, const uint32_t* lut, const uint32
     const uint32_t n = sh.n;
     const uint32_t dAB = (uint32_t)(offB - offA);                     // record B starts this far behind record A (the true length of A)
     const uint32_t voff = hb ? dAB : 0u;
-    const uint32_t rel = (uint32_t)offA - base_lo + voff, a16 = rel & 15, nch = (a16 + n + 15) >> 4;      // chunks the record touches: <= 64
+    const uint32_t relA = (uint32_t)offA - base_lo, rel = relA + voff, a16 = rel & 15;
     const uint32_t* cp = img + 4 * ((rel >> 4) + 2 * u);
     uint32_t ms0, ms1;
     const uint32_t P0 = fast_pack(lds_load16(cp), ms0), P1 = fast_pack(lds_load16(cp + 4), ms1);
+#if CK_PAIR_SCALAR_VALID
+    // Which lanes' chunks belong to their record -- chunk 2u / 2u+1 of nch = (a16 + n + 15) / 16 <= 64 --: wave masks from the
+    // two records' scalars.  (EXPERIMENT, off: eight more scalar registers live across the loop, which the compiler pays for in
+    // v_writelane / v_readlane spill traffic -- vector instructions: hash only 3.39 -> 3.53 ms.)
+    const uint32_t nchA = ((relA & 15) + nA + 15) >> 4, nchB = (((relA + dAB) & 15) + nB + 15) >> 4;
+    const auto low32 = [](uint32_t k) -> uint64_t { return k >= 32 ? 0xFFFFFFFFull : (1ull << k) - 1; };
+    const uint64_t in0 = low32((nchA + 1) >> 1) | (low32((nchB + 1) >> 1) << 32), in1 = low32(nchA >> 1) | (low32(nchB >> 1) << 32);
+    const uint64_t badm = (ballot(ms0 != 0) & in0) | (ballot(ms1 != 0) & in1);
+#else
     // (the first and last chunk also hold the neighbours' bytes: an invalid byte there defers the record for nothing -- harmless)
+    const uint32_t nch = (a16 + n + 15) >> 4;                         // chunks the record touches: <= 64
     const uint64_t badm = ballot(((ms0 != 0) & (2 * u < nch)) | ((ms1 != 0) & (2 * u + 1 < nch)));
+#endif
     uint32_t ok = elig & (((uint32_t)badm == 0 ? 1u : 0u) | ((uint32_t)(badm >> 32) == 0 ? 2u : 0u));
     // the record starts a16 bytes into its first chunk: removed on the packed words
     const uint32_t sh2 = 32 - 2 * a16;
@@ -233,10 +247,12 @@ CK_DEV uint32_t pair_canon(const CanonArgs& a, const uint32_t* lut, const uint32
         const u32x4 cell = fast_decode(lut, pair_window(S, p));
         if (outA != nullptr && lane_pred(okm & sh.in_rec[k])) store16(outA + (voff + o), cell);
         if (hashing && lane_pred(sh.on[k])) {
+            // acc0 += d1 + lo(d0 ^ k0) * hi(d0 ^ k0), acc1 += d0 + lo(d1 ^ k1) * hi(d1 ^ k1) (XXH3's accumulate; the products go in
+            // through the multiply-add's own addend)
             const uint64_t d0 = ((uint64_t)cell.y << 32) | cell.x, d1 = ((uint64_t)cell.w << 32) | cell.z;
             const uint64_t x0 = d0 ^ kp[8 * k], x1 = d1 ^ kp[8 * k + 1];
-            c0 += d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32);
-            c1 += d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32);
+            c0 = (uint64_t)(uint32_t)x0 * (x0 >> 32) + (c0 + d1);
+            c1 = (uint64_t)(uint32_t)x1 * (x1 >> 32) + (c1 + d0);
         }
     }
     if (hashing) {
