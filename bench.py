@@ -471,12 +471,12 @@ def cli_block(np, torch, d_bytes, d_out, N, L):
         res = {"input": "%d records x %d b, %d bytes of FASTA in /dev/shm (the headline batch's first records)" % (R, L, R * (L + 11)),
                "threads": "default (the CPUs this process may use)"}
         env = dict(os.environ, CIRCKIT_CLI_TIMING="1")
-        for sink, target in (("dev_null", "/dev/null"), ("tmpfs_file", dst)):
+        for sink, target, cmd in (("dev_null", "/dev/null", "canonicalize"), ("tmpfs_file", dst, "canonicalize"), ("uniq_dev_null", "/dev/null", "uniq")):
             t0 = time.perf_counter()
-            r = subprocess.run([exe, "canonicalize", src, "-o", target], capture_output=True, env=env)
+            r = subprocess.run([exe, cmd, src, "-o", target], capture_output=True, env=env)
             dt = time.perf_counter() - t0
             if r.returncode != 0:
-                return {"error": "circkit canonicalize failed: %s" % r.stderr.decode(errors="replace")[-300:]}
+                return {"error": "circkit %s failed: %s" % (cmd, r.stderr.decode(errors="replace")[-300:])}
             res[sink] = {"wall_s": dt, "records_per_s": R / dt, "gbytes_per_s": R * (L + 11) / dt / 1e9}
             # the binary's own clock (CIRCKIT_CLI_TIMING): main() up to the last byte written, the HIP / context start-up inside it
             # (runs next to reading and parsing) and the pipeline behind it
