@@ -822,3 +822,25 @@ def test_pair_build_two_records_per_wave(staged, hash_only):
             assert int(h[i]) == O.xxh3_64(c), (i, len(s), s[:60])
         if hash_only:
             assert (out == 0x3F).all()
+
+
+def test_pair_build_every_length():
+    """canon_pair.h's lane constants (periodic extension, reverse-strand windows, output cells, XXH3 stripes) are functions of the
+    two record lengths: every length 48..1008 once in either half, next to a partner of another length, bytes and hashes."""
+    import random
+    rng = random.Random(5150)
+    lens = list(range(48, 1009))
+    rng.shuffle(lens)
+    seqs = []
+    for i, n in enumerate(lens):
+        a, b = seqsets.rand_seq(rng, n), seqsets.rand_seq(rng, rng.randint(48, 1008))
+        seqs += [a, b] if i % 2 else [b, a]
+    seqs += [seqsets.rand_seq(rng, 500)] * 0 + [seqsets.rand_seq(rng, 700) for _ in range(16)]     # (the last group is never staged)
+    data, offs = seqsets.pack(seqs)
+    out, _, _, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=True, want_aux=False, staged=15, slice_dw=4096, n_waves=8)
+    assert status == 0 and ndef == 0
+    assert emu.last_fast_count >= len(seqs) - 16 - 60                                  # (tied 8- and 16-symbol minima are rare)
+    for i, s in enumerate(seqs):
+        c = seqsets.expected(O, s)[0]
+        assert out[int(offs[i]):int(offs[i + 1])].tobytes() == c, (i, len(s))
+        assert int(h[i]) == O.xxh3_64(c), (i, len(s))
