@@ -676,7 +676,8 @@ void pass_signal(int sig) { if (g_worker > 0) kill(g_worker, sig); }
 void report_done()                   // worker, after the last close
 {
     if (g_done_fd < 0) return;
-    (void)close(STDOUT_FILENO);      // (a reader of our stdout must not wait for the teardown either)
+    (void)close(STDOUT_FILENO);      // (a reader of our stdout must not wait for the teardown either,
+    (void)close(STDERR_FILENO);      //  nor one that collects our messages: nothing is said after this point)
     const unsigned char ok = 0;
     ssize_t w;
     do w = write(g_done_fd, &ok, 1); while (w < 0 && errno == EINTR);
