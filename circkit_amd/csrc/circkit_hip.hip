@@ -245,6 +245,14 @@ using StreamCH = ck::StreamCfg<CK_STREAM_WPB_HASH, CK_STREAM_NBUF, CK_STREAM_RPW
 // ... and, for batches of pure ACGT, take TWO records per wave, one per half-wave (canon_pair.h): the scalar side of an iteration
 // and the vector work that does not depend on the bytes are shared by two records.  CK_STREAM_WPB_PAIR waves, groups of twice as
 // many records; CK_PAIR_WPE waves per SIMD (the register budget the build is compiled for).  CK_STREAM_WPB_PAIR 0: no such build.
+// The bytes-only N build (MODE_ALPHA batches): 4 waves.  A record with an N among the symbols that decide (one in
+// thirteen at 1 % N) takes the 4-bit routine behind the N-mask routine -- twice the work --, and the workgroup's barrier makes every
+// wave wait for it: with 16 waves 72 % of the iterations hold such a record, with 8 waves 47 %, with 4 waves 27 % (10M x 1 kb, 1 % N, one
+// box: 16 waves 4.90 ms, 8 waves 4.65, 4 waves 4.56, 2 waves 4.70).
+#ifndef CK_STREAM_WPB_ALPHA
+#define CK_STREAM_WPB_ALPHA 4
+#endif
+using StreamCA = ck::StreamCfg<CK_STREAM_WPB_ALPHA, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
 #ifndef CK_STREAM_WPB_PAIR
 #define CK_STREAM_WPB_PAIR 8
 #endif
@@ -502,7 +510,7 @@ CK_MIXED_KERNEL(canon_mixed_nh_kernel, true, true, CK_MIXED_NM_VGPR)
 // ALPHA (ROWS = 1, no index / strand outputs): the build for batches with MODE_ALPHA -- records with N or '-' take the
 // 4-bit register routine inside the staged loop.  The builds without it answer for every other batch, MODE_ALPHA or not.
 template <class StreamC, bool HASH, bool AUX, bool PERSIST, bool ALPHA = false>
-__global__ __launch_bounds__(StreamC::WPB * 64, (HASH && !AUX && !ALPHA && StreamC::ROWS == 1 && StreamC::RPW == 2) ? CK_PAIR_WPE : StreamC::WPB >= 8 ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
+__global__ __launch_bounds__(StreamC::WPB * 64, (HASH && !AUX && !ALPHA && StreamC::ROWS == 1 && StreamC::RPW == 2) ? CK_PAIR_WPE : (StreamC::WPB >= 8 || (ALPHA && !HASH && !AUX)) ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
                                                                                                              uint32_t host_mode, uint32_t nvb)
 {
     const uint32_t bm = batch_mode(mode, host_mode);
@@ -1332,7 +1340,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const uint32_t seen = *c->h_mode;
         const uint32_t expect = host_mode ? host_mode & 3 : ((seen & 3) ? seen & 3 : 1u);
         const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
-        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64), block_h(StreamCH::WPB * 64), block_hp(StreamCHP::WPB * 64);
+        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64), block_h(StreamCH::WPB * 64), block_hp(StreamCHP::WPB * 64), block_a(StreamCA::WPB * 64);
         // (rows, alphabet) builds: ROWS = 1 lean, ROWS = 1 with the 4-bit routine, ROWS = 2.  The host's answer launches
         // exactly one; a device-side decision launches all three, full-size where the previous batch's mode says it will run
         const uint32_t expect_alpha = host_mode ? host_mode & MODE_ALPHA : seen & MODE_ALPHA;
@@ -1350,7 +1358,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                 if (rows == 1) {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux, false);
                     else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamCH, true, false, block_h, true); else CK_LAUNCH_STREAM(StreamCHP, true, false, block_hp, false); }
-                    else { if (alpha) CK_LAUNCH_STREAM(StreamC, false, false, block, true); else if (CK_STREAM_PAIR_BYTES) CK_LAUNCH_STREAM(StreamCHP, false, false, block_hp, false); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
+                    else { if (alpha) CK_LAUNCH_STREAM(StreamCA, false, false, block_a, true); else if (CK_STREAM_PAIR_BYTES) CK_LAUNCH_STREAM(StreamCHP, false, false, block_hp, false); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
                 } else {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux, false);
                     else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block, false);

@@ -206,6 +206,8 @@ const StreamVariant kStream[] = {
     variant<ck::StreamCfg<8, 2, 1>>(),
     // ... and of the pair build: 4 waves, two records each (one per half-wave), groups of 8
     variant<ck::StreamCfg<4, 2, 2>>(), variant<ck::StreamCfg<8, 2, 2>>(),
+    // the bytes-only N build's: 4 waves, one record each, two images
+    variant<ck::StreamCfg<4, 2, 1>>(),
 };
 }
 
