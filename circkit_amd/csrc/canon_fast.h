@@ -161,9 +161,27 @@ CK_DEV void group_hash_put(uint32_t* slot, uint64_t k0, uint64_t k1, u32x4 cell,
     slot[64 + t] = E;
     if (t == 0) { slot[128] = n; slot[129] = idx; slot[130] = 1; }
 }
+// ... for a record with N (the streaming build for MODE_ALPHA batches): the strand in the slot would decode to G / C where the
+// record holds N, so the producer leaves the last stripe's 64 BYTES (patched like the cells it stores) in [64,80) instead of the
+// strand: `last` = the 16 bytes at output offset n - 64 + 16 * (lane & 3), the same in every lane of a quad
+CK_DEV void group_hash_put_bytes(uint32_t* slot, uint64_t k0, uint64_t k1, u32x4 cell, u32x4 last, uint32_t n)
+{
+    const uint32_t t = lane_id();
+    const uint32_t stripes = (n - 1) >> 6;
+    const uint64_t d0 = ((uint64_t)cell.y << 32) | cell.x, d1 = ((uint64_t)cell.w << 32) | cell.z;
+    const uint64_t x0 = d0 ^ k0, x1 = d1 ^ k1;
+    const bool on = t < 4 * stripes;
+    uint64_t c0 = on ? d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32) : 0;
+    uint64_t c1 = on ? d0 + (uint64_t)(uint32_t)x1 * (x1 >> 32) : 0;
+    dpp_rowsum4_u64x2(c0, c1);
+    if ((t & 15) >= 12) lds_store16(slot + (t >> 4) * 16 + (t & 3) * 4, u32x4{ (uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32) });
+    if (t < 4) lds_store16(slot + 64 + 4 * t, last);
+    if (t == 0) { slot[128] = n; slot[129] = 0; slot[130] = 1; }
+}
 // merger: finishes the GROUP records of `slots` (records rec0 .. rec0 + GROUP - 1 of the batch)
+// LASTB: the producers are group_hash_put_bytes
 // NROWS: 16-lane rows of partial sums a producer leaves per record (4: one record per wave; 2: canon_pair.h, one per half-wave)
-template <int GROUP, int NROWS = 4>
+template <int GROUP, int NROWS = 4, bool LASTB = false>
 CK_DEV void group_hash_merge(const CanonArgs& a, const uint32_t* lut, const uint32_t* ghc, const uint32_t* slots, uint32_t rec0)
 {
     static_assert(GROUP <= 16, "one lane per (record, accumulator pair)");
@@ -180,10 +198,14 @@ CK_DEV void group_hash_merge(const CanonArgs& a, const uint32_t* lut, const uint
         a1 += ((uint64_t)v.w << 32) | v.z;
     }
     {   // last stripe: the final 64 bytes, pair j = bytes [n-64+16j, n-48+16j)
-        uint32_t p = idx + (n - 64) + 16 * j;
-        p = p >= n ? p - n : p;
-        const uint32_t wi = p >> 4;
-        const u32x4 b = fast_decode(lut, lshr64(s[64 + wi], s[64 + wi + 1], 32 - (p & 15) * 2));
+        u32x4 b;
+        if constexpr (LASTB) b = lds_load16(s + 64 + 4 * j);
+        else {
+            uint32_t p = idx + (n - 64) + 16 * j;
+            p = p >= n ? p - n : p;
+            const uint32_t wi = p >> 4;
+            b = fast_decode(lut, lshr64(s[64 + wi], s[64 + wi + 1], 32 - (p & 15) * 2));
+        }
         const uint64_t d0 = ((uint64_t)b.y << 32) | b.x, d1 = ((uint64_t)b.w << 32) | b.z;
         const uint64_t x0 = d0 ^ (((uint64_t)cl.y << 32) | cl.x), x1 = d1 ^ (((uint64_t)cl.w << 32) | cl.z);
         a0 += d1 + (uint64_t)(uint32_t)x0 * (x0 >> 32);
@@ -283,7 +305,7 @@ template <bool HASH, bool AUX, bool GH = false, bool K16 = false, bool NM = fals
 CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashConst& hc, FastShape& sh, uint32_t rec, uint64_t off,
                        uint32_t n, uint32_t F, uint64_t bad, uint32_t* gh_slot = nullptr, uint32_t Nm = 0, uint32_t* view_out = nullptr)
 {
-    static_assert(!NM || (!HASH && !AUX), "the N-mask variant writes bytes only");
+    static_assert(!NM || (!AUX && (!HASH || GH)), "the N-mask variant: bytes, and the XXH3 only through the group merger (group_hash_put_bytes)");
     const uint32_t t = lane_id();
     const uint32_t nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
     if (sh.n != n) fast_shape(sh, n);
@@ -380,22 +402,28 @@ CK_DEV bool fast_canon(const CanonArgs& a, const uint32_t* lut, const FastHashCo
         const bool hash = HASH && a.out_hash != nullptr && n > 240;     // XXH3's long-input path; shorter: xxh3 pass
         const bool store = a.out_bytes != nullptr;
         if (store || hash) {
-            u32x4 cell = fast_decode(lut, reg_sym_word(E, idx + o, n));
-            if constexpr (NM) {
-                const uint32_t m = reg_sym_word(Em, idx + o, n);
-                if (m) {
-                    // the decoded 'G' (forward) or 'C' (reverse) of every marked symbol becomes 'N': bit 2j of a reversed
-                    // mask byte -> 0x01 in byte j by one multiplication (1 + 2^6 + 2^12 + 2^18), times the XOR constant
-                    const uint32_t rm = bitrev(m), fix = fwd ? 0x09u : 0x0Du;
-                    cell.x ^= (((rm & 0x55u) * 0x41041u) & 0x01010101u) * fix;
-                    cell.y ^= ((((rm >> 8) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
-                    cell.z ^= ((((rm >> 16) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
-                    cell.w ^= ((((rm >> 24) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+            // the 16 output bytes at output offset q (NM: the decoded 'G' (forward) or 'C' (reverse) of every marked symbol becomes
+            // 'N': bit 2j of a reversed mask byte -> 0x01 in byte j by one multiplication (1 + 2^6 + 2^12 + 2^18), times the XOR constant)
+            const auto cell_at = [&](uint32_t q) {
+                u32x4 c = fast_decode(lut, reg_sym_word(E, idx + q, n));
+                if constexpr (NM) {
+                    const uint32_t m = reg_sym_word(Em, idx + q, n);
+                    if (m) {
+                        const uint32_t rm = bitrev(m), fix = fwd ? 0x09u : 0x0Du;
+                        c.x ^= (((rm & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                        c.y ^= ((((rm >> 8) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                        c.z ^= ((((rm >> 16) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                        c.w ^= ((((rm >> 24) & 0x55u) * 0x41041u) & 0x01010101u) * fix;
+                    }
                 }
-            }
+                return c;
+            };
+            const u32x4 cell = cell_at(o);
             if (store && valid) store16(a.out_bytes + off + o, cell);
             if (hash) {
-                if constexpr (GH) {
+                if constexpr (GH && NM) {
+                    group_hash_put_bytes(gh_slot, hc.k0, hc.k1, cell, cell_at(n - 64 + 16 * (t & 3)), n);      // (n > 240: the offset is in range)
+                } else if constexpr (GH) {
                     group_hash_put(gh_slot, hc.k0, hc.k1, cell, E, idx, n);
                 } else {
                     const uint64_t h = fast_hash(hc, lut, cell, E, idx, n);

@@ -304,20 +304,24 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                 // chunks 0 and nch-1 also hold bytes of the neighbouring records: an invalid byte there sends this
                 // record to the general kernel for nothing, which is harmless
                 uint64_t bad;                       // lanes with a byte the 2-bit routines cannot take
-                if constexpr (ALPHA && !HASH && !AUX) {
+                if constexpr (ALPHA && !AUX && (!HASH || GH)) {
                     // N is the usual stranger: ONE packing pass gives the 2-bit words with N as G plus the mask, and the
                     // register routine's N-mask variant takes the record (220 VALU per record against 255 with the 4-bit
                     // routine below, and 16-symbol keys instead of 8: hardly a tie).  A batch of this build holds an N in
                     // most records; the few without take the plain routine.  What the variant refuses -- an N among the
-                    // deciding symbols -- and records with a gap go to the 4-bit routine.
+                    // deciding symbols -- and records with a gap go to the 4-bit routine.  (With the XXH3, end of round 4: the
+                    // hash is fused for records with N too -- group_hash_put_bytes; before, every such record took the 4-bit
+                    // routine and a pass of the xxh3 kernel over its bytes: `uniq` on 10M x 1 kb with 1 % N 10.8 ms.)
                     uint32_t nm, miss2;
                     const uint32_t Pn = fast_pack_n2(v, nm, miss2);
                     bad = ballot(miss2 != 0) & chunks;
                     const uint64_t with_n = ballot(nm != 0) & chunks;
                     if (bad == 0) {
                         const uint32_t Fw = lshr64(Pn, wave_shl1(Pn), 32 - 2 * a16);
-                        if (with_n == 0) done = fast_canon<false, false, false, true, false, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr);
-                        else done = fast_canon<false, false, false, true, true, true>(a, lut, hc, shape, rec, off, n, Fw, 0, nullptr, lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
+                        // (with the XXH3 every record of the build leaves its last stripe as bytes -- the merger is built for that --, so
+                        // the few without an N take the N-mask variant with an empty mask)
+                        if (!HASH && with_n == 0) done = fast_canon<HASH, false, GH, true, false, true>(a, lut, hc, shape, rec, off, n, Fw, 0, slot);
+                        else done = fast_canon<HASH, false, GH, true, true, true>(a, lut, hc, shape, rec, off, n, Fw, 0, slot, lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
                     }
                     bad |= with_n;                  // (what the 4-bit routine is for)
                 } else {
@@ -346,7 +350,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
         // the previous group's hashes: its slots were complete at the barrier that ended the previous iteration
         if constexpr (GH) {
             if (it > 0 && w == ((it - 1) & (C::WPB - 1)))
-                group_hash_merge<(int)C::GROUP, PAIR ? 2 : 4>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, (g - nblocks) * C::GROUP);
+                group_hash_merge<(int)C::GROUP, PAIR ? 2 : 4, GH && ALPHA>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, (g - nblocks) * C::GROUP);
         }
         // the next group's DMAs (issued D-1 iterations ago) must have landed.  Younger vector-memory instructions:
         // the DMAs of the D-1 groups issued since (DPW each), and the stores of this and the D-1 previous iterations
@@ -375,7 +379,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     if constexpr (GH) {
         if (it > 0 && w == ((it - 1) & (C::WPB - 1))) {             // the last group's hashes (behind the loop's final barrier)
             const uint32_t g_last = block + (it - 1) * nblocks;
-            group_hash_merge<(int)C::GROUP, PAIR ? 2 : 4>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, g_last * C::GROUP);
+            group_hash_merge<(int)C::GROUP, PAIR ? 2 : 4, GH && ALPHA>(a, lut, gh_const, gh + (((it - 1) & 1) * C::GROUP) * GH_STRIDE_DW, g_last * C::GROUP);
         }
     }
 }

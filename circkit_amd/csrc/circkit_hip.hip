@@ -239,7 +239,7 @@ using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
 // every box measured, bytes + hash -2 % .. 0.  The bytes-only builds are bound by the memory system and keep 16 waves (-1 % on one
 // box, +3.5 % on another).
 #ifndef CK_STREAM_WPB_HASH
-#define CK_STREAM_WPB_HASH 8
+#define CK_STREAM_WPB_HASH 4
 #endif
 using StreamCH = ck::StreamCfg<CK_STREAM_WPB_HASH, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
 // ... and, for batches of pure ACGT, take TWO records per wave, one per half-wave (canon_pair.h): the scalar side of an iteration
@@ -510,7 +510,7 @@ CK_MIXED_KERNEL(canon_mixed_nh_kernel, true, true, CK_MIXED_NM_VGPR)
 // ALPHA (ROWS = 1, no index / strand outputs): the build for batches with MODE_ALPHA -- records with N or '-' take the
 // 4-bit register routine inside the staged loop.  The builds without it answer for every other batch, MODE_ALPHA or not.
 template <class StreamC, bool HASH, bool AUX, bool PERSIST, bool ALPHA = false>
-__global__ __launch_bounds__(StreamC::WPB * 64, (HASH && !AUX && !ALPHA && StreamC::ROWS == 1 && StreamC::RPW == 2) ? CK_PAIR_WPE : (StreamC::WPB >= 8 || (ALPHA && !HASH && !AUX)) ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
+__global__ __launch_bounds__(StreamC::WPB * 64, (HASH && !AUX && StreamC::ROWS == 1 && (ALPHA || StreamC::RPW == 2)) ? CK_PAIR_WPE : (StreamC::WPB >= 8 || (ALPHA && !HASH && !AUX)) ? CK_FAST_WPE : 4) void canon_stream_kernel(ck::CanonArgs a, const uint32_t* __restrict__ mode,
                                                                                                              uint32_t host_mode, uint32_t nvb)
 {
     const uint32_t bm = batch_mode(mode, host_mode);

@@ -844,3 +844,40 @@ def test_pair_build_every_length():
         c = seqsets.expected(O, s)[0]
         assert out[int(offs[i]):int(offs[i + 1])].tobytes() == c, (i, len(s))
         assert int(h[i]) == O.xxh3_64(c), (i, len(s))
+
+
+@pytest.mark.parametrize("staged", [1, 13, 16])
+@pytest.mark.parametrize("hash_only", [False, True])
+def test_streaming_n_build_fuses_the_hash_of_records_with_n(staged, hash_only):
+    """`uniq` on a batch with N (MODE_ALPHA): the N-mask variant of the register routine leaves the XXH3 of a record WITH N to the
+    workgroup's merger like any other -- row sums of the patched cells, and the last stripe as patched bytes (group_hash_put_bytes:
+    the strand in the slot would decode to G / C where the record holds N).  Before, every such record took the 4-bit routine and a
+    pass of the xxh3 kernel over its bytes.  N in the last 64 bytes, in the first cell, next to the wrap; records without N in the
+    same build; the ones the variant refuses (an N among the deciding symbols, a gap) still come out right through the 4-bit
+    routine and the xxh3 pass."""
+    import random
+    rng = random.Random(6100 + staged)
+    seqs = []
+    for i in range(120):
+        n = rng.choice([1000, 1000, 1000, 241, 256, 300, 777, 1008, rng.randint(241, 1008)])
+        s = bytearray(seqsets.rand_seq(rng, n))
+        for _ in range(rng.choice([0, 1, 1, 2, 5, 10, 30])):
+            s[rng.randrange(n)] = ord("N")
+        if i % 7 == 0:
+            for p in (n - 1, n - 17, n - 64, 0, 15, 16):
+                s[p] = ord("N")
+        if i % 23 == 0:
+            s[rng.randrange(n)] = ord("-")
+        seqs.append(bytes(s))
+    seqs += [seqsets.rand_seq(rng, 1000) for _ in range(8)] + [b"N" * 500, b"ACGTN" * 100]
+    data, offs = seqsets.pack(seqs)
+    out, _, _, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=True, want_aux=False, staged=staged, slice_dw=4096, n_waves=8,
+                                                        alpha=True, hash_only=hash_only)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        c = seqsets.expected(O, s)[0]
+        if not hash_only:
+            assert out[int(offs[i]):int(offs[i + 1])].tobytes() == c, (i, len(s))
+        assert int(h[i]) == O.xxh3_64(c), (i, len(s))
+    with_n = sum(1 for s in seqs[:len(seqs) // 16 * 16 - 16] if b"N" in s and b"-" not in s)
+    assert emu.last_fused_hash_count >= with_n * 2 // 3, (emu.last_fused_hash_count, with_n)      # (an N among the deciding symbols: one record in ten or so)
