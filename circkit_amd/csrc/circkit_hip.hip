@@ -290,6 +290,14 @@ __host__ __device__ inline uint32_t stream_mode(uint64_t two, uint64_t lng, uint
 // which leaves the odd N-bearing record to the LDS tiers (carrying the 4-bit path costs the lean one 25-45 %, measured).
 constexpr uint32_t CONTENT_SAMPLES = 4096, MODE_ALPHA = 4;
 __host__ __device__ inline uint32_t alpha_mode(uint64_t bad, uint64_t sampled) { return bad && bad * 16 >= sampled ? MODE_ALPHA : 0u; }
+// The batch's mode from the samples.  The two-word build of the streaming kernel has no alphabet twin -- its records with an N went
+// to LDS stage A one by one (6M x 1.5 kb with 1 % N: 11.9 ms, 0.19 of peak) --, the mixed-length kernels have one: a batch of
+// two-word records WITH N is theirs (mode 3).
+__host__ __device__ inline uint32_t batch_mode_of(uint64_t two, uint64_t lng, uint64_t n, uint64_t bad, uint64_t sampled)
+{
+    const uint32_t m = stream_mode(two, lng, n), al = alpha_mode(bad, sampled);
+    return (m == 2 && al ? 3u : m) | al;
+}
 // ctl: [0] two-word records among the samples, [1] longer ones, [2] arrival ticket, [3] content samples with a byte
 // outside ACGT -- all zero on entry and on exit; *mode receives stream_mode() | alpha_mode() of the samples (written by
 // the workgroup that arrives last), counters[0] (records beyond the LDS tiers) and counters[3] (records nothing could
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(ctl + 2, 1u) == gridDim.x - 1) {
             const uint32_t t2 = atomicExch(ctl, 0u), tl = atomicExch(ctl + 1, 0u), tb = atomicExch(ctl + 3, 0u);
-            *mode = stream_mode(t2, tl, ns) | alpha_mode(tb, nc);
+            *mode = batch_mode_of(t2, tl, ns, tb, nc);
             atomicExch(ctl + 2, 0u);
         }
     }
@@ -589,6 +597,23 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
         // round trip in front of every record
         const uint64_t my_off = need ? offsets[mine] : 0;
         const uint32_t my_len = need ? (uint32_t)(offsets[mine + 1] - my_off) : 0u;
+        // XXH3's short-input classes (<= 240 bytes) are ONE scalar recipe (xxh3_short): every lane hashes its own record instead of
+        // the whole wave hashing one after the other -- a batch of short reads (20M x 200 b, none of whose hashes the kernels
+        // in front fuse) took 58 ms with bytes, 89 ms from views; ~60 times fewer instructions this way
+        const bool mine_short = need && my_len <= 240u;
+        const uint64_t shorts = ck::ballot(mine_short);
+        if (shorts) {
+            if (mine_short) {
+                const uint8_t* p = bytes + my_off;
+                uint64_t h;
+                if (view) {
+                    const uint32_t v = view[mine], rot = v & 0x7FFFFFFFu;
+                    h = ck::xxh3_short(ck::XView{ p, my_len, rot < my_len ? rot : 0u, (v >> 31) != 0, comp }, my_len);
+                } else h = ck::xxh3_short(ck::XPlain{ p }, my_len);
+                out[mine] = h;
+            }
+            todo &= ~shorts;
+        }
         while (todo) {
             const uint32_t l = (uint32_t)ck::ffs64(todo);
             todo &= todo - 1;
@@ -1734,7 +1759,7 @@ int host_batch_enqueue(circkit_ctx* c, const uint8_t* bytes, const uint64_t* off
             bad += b;
         }
     }
-    const uint32_t host_mode = stream_mode(two_word, longer, n) | alpha_mode(bad, nc);
+    const uint32_t host_mode = batch_mode_of(two_word, longer, n, bad, nc);
     dbg_lap("content sample");
     volatile uint32_t* unprocessed = c->h_mode + 4;                       // (pinned)
     for (int k = 0; k < parts; ++k) {

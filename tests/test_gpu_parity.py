@@ -721,9 +721,9 @@ def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
     one the previous batch used with the full-size grid)."""
     import torch
     from tests import seqsets
-    seqs = seqsets.random_mixed(101, 600, 1009, 2032) + seqsets.random_mixed(102, 60, 1009, 2032, b"ACGTN") + \
+    seqs = seqsets.random_mixed(101, 600, 1009, 2032) + seqsets.random_mixed(102, 30, 1009, 2032, b"ACGTN") + \
         seqsets.random_mixed(103, 100, 48, 1008) + seqsets.random_mixed(104, 30, 2033, 2600) + \
-        [b"ACGT" * 400, b"A" * 1500, seqsets.random_mixed(105, 1, 1164, 1164)[0] * 1]
+        [b"ACGT" * 400, b"A" * 1500, seqsets.random_mixed(105, 1, 1164, 1164)[0] * 1]          # (one record in 25 with an N: below the alphabet rule's one in 16)
     _check(ctx, O, seqs)                                            # host API, every output
     data, offs = seqsets.pack(seqs)
     n = len(seqs)
@@ -738,6 +738,24 @@ def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
         ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep else None)
         torch.cuda.synchronize()
         assert ctx.last_batch_mode() == 2
+        assert np.array_equal(d_out.cpu().numpy(), exp), rep
+        if rep:
+            assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    # the two-word build has no alphabet twin: a batch of such records in which N is common (one record in sixteen or more) is the
+    # mixed-length N kernels' (mode 3) -- left to the two-word build its N records went to LDS stage A one by one (6M x 1.5 kb with
+    # 1 % N: 11.9 ms; 6.3 through mode 3)
+    seqs = seqsets.random_mixed(111, 400, 1009, 2032) + seqsets.random_mixed(112, 300, 1009, 2032, b"ACGTN") + seqsets.random_mixed(113, 60, 48, 1008, b"ACGTN")
+    data, offs = seqsets.pack(seqs)
+    n = len(seqs)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
+    for rep in range(3):
+        d_out = torch.zeros_like(d_bytes)
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep else None)
+        torch.cuda.synchronize()
+        assert ctx.last_batch_mode() == 3 and ctx.batch_status() == 0
         assert np.array_equal(d_out.cpu().numpy(), exp), rep
         if rep:
             assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
