@@ -30,9 +30,6 @@ namespace ck {
 #ifndef CK_STREAM_TOUCH
 #define CK_STREAM_TOUCH 1
 #endif
-#ifndef CK_STREAM_PAIR_BYTES
-#define CK_STREAM_PAIR_BYTES 0     // EXPERIMENT: two records per wave (canon_pair.h) in the bytes-only build too
-#endif
 template <int WPB_, int NBUF_, int RPW_ = 2, int ROWS_ = 1>
 struct StreamCfg {
     static constexpr int WPB = WPB_, RPW = RPW_, NBUF = NBUF_;
@@ -151,8 +148,10 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
     static_assert(C::RPW == 1 || C::RPW == 2, "one or two records per wave per group");
     static_assert(!GH || (HASH && !AUX && C::ROWS == 1 && C::GROUP <= 16), "the group merger takes up to 16 records of one packed word per 16 symbols");
     // GH with two records per wave: canon_pair.h -- one record per half-wave, both at once
-    // ... and, CK_STREAM_PAIR_BYTES, the bytes-only build of such a geometry as well (gh = PAIR_SCRATCH_DW dwords per record then)
-    constexpr bool PAIR_B = CK_STREAM_PAIR_BYTES && !HASH && !AUX && !ALPHA && C::ROWS == 1 && C::RPW == 2;
+    // ... and the bytes-only build of such a geometry as well (gh = PAIR_SCRATCH_DW dwords per record then): the build for batches of
+    // SHORT records (circkit_hip.hip MODE_SHORT -- a record of 300 symbols keeps 19 of a wave's 64 lanes busy, two of them 20 of 32
+    // each: 20M x 200 b 6.14 -> 4.84 ms, 10M x 400 b 3.34 -> 2.68; from ~850 symbols on one record per wave is faster)
+    constexpr bool PAIR_B = !HASH && !AUX && !ALPHA && C::ROWS == 1 && C::RPW == 2;
     constexpr bool PAIR = (GH && C::RPW == 2) || PAIR_B;
     static_assert(!PAIR || !ALPHA, "the pair routine takes pure ACGT only (the ALPHA build keeps one record per wave)");
     constexpr int SPW = PAIR ? 1 : C::RPW;            // vector-memory stores every wave is SURE to issue per iteration (pair: cell 0 of a finished record, or a deferral)

@@ -289,14 +289,17 @@ __host__ __device__ inline uint32_t stream_mode(uint64_t two, uint64_t lng, uint
 // MODE_ALPHA and the rescue pass runs its build with the 4-bit register path (canon_stream.h); otherwise the lean build,
 // which leaves the odd N-bearing record to the LDS tiers (carrying the 4-bit path costs the lean one 25-45 %, measured).
 constexpr uint32_t CONTENT_SAMPLES = 4096, MODE_ALPHA = 4;
+// MODE_SHORT (mode 1, no MODE_ALPHA): most of the batch's records are short -- the bytes-only streaming kernel then runs its pair
+// build (two records per wave, canon_pair.h); records of up to SHORT_MAX_N symbols count as short, half of the samples make the mode
+constexpr uint32_t MODE_SHORT = 8, SHORT_MAX_N = 800;
 __host__ __device__ inline uint32_t alpha_mode(uint64_t bad, uint64_t sampled) { return bad && bad * 16 >= sampled ? MODE_ALPHA : 0u; }
 // The batch's mode from the samples.  The two-word build of the streaming kernel has no alphabet twin -- its records with an N went
 // to LDS stage A one by one (6M x 1.5 kb with 1 % N: 11.9 ms, 0.19 of peak) --, the mixed-length kernels have one: a batch of
 // two-word records WITH N is theirs (mode 3).
-__host__ __device__ inline uint32_t batch_mode_of(uint64_t two, uint64_t lng, uint64_t n, uint64_t bad, uint64_t sampled)
+__host__ __device__ inline uint32_t batch_mode_of(uint64_t two, uint64_t lng, uint64_t n, uint64_t bad, uint64_t sampled, uint64_t shortc)
 {
     const uint32_t m = stream_mode(two, lng, n), al = alpha_mode(bad, sampled);
-    return (m == 2 && al ? 3u : m) | al;
+    return (m == 2 && al ? 3u : m) | al | (m == 1 && !al && shortc * 2 >= n ? MODE_SHORT : 0u);
 }
 // ctl: [0] two-word records among the samples, [1] longer ones, [2] arrival ticket, [3] content samples with a byte
 // outside ACGT -- all zero on entry and on exit; *mode receives stream_mode() | alpha_mode() of the samples (written by
@@ -305,18 +308,19 @@ __host__ __device__ inline uint32_t batch_mode_of(uint64_t two, uint64_t lng, ui
 __global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n, uint32_t* ctl,
                                                             uint32_t* mode, uint32_t* counters)
 {
-    __shared__ uint32_t blk[3];
-    if (threadIdx.x < 3) blk[threadIdx.x] = 0;
+    __shared__ uint32_t blk[4];
+    if (threadIdx.x < 4) blk[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 3) { counters[0] = 0; counters[1] = 0; counters[3] = 0; counters[16] = 0; counters[17] = 0; }      // ([16], [17]: the mixed N builds' segment ticket -- self-zeroing, zeroed here as well)
     __syncthreads();
     const uint32_t shift = count_shift(n);
     const uint64_t ns = count_samples(n);
-    uint32_t two = 0, lng = 0;          // records of 1009..2032 bases / longer ones (no build can stage their group)
+    uint32_t two = 0, lng = 0, sht = 0; // records of 1009..2032 bases / longer ones (no build can stage their group) / short ones
     for (uint64_t j = (uint64_t)blockIdx.x * 1024 + threadIdx.x; j < ns; j += (uint64_t)gridDim.x * 1024) {
         const uint64_t i = j << shift;
         const uint64_t len = offsets[i + 1] - offsets[i];
         two += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
         lng += len > ck::FAST2_MAX_N;
+        sht += len <= SHORT_MAX_N;
     }
     // content samples: record k * cstep, one wave each
     const uint64_t nc = n < CONTENT_SAMPLES ? n : CONTENT_SAMPLES, cstep = n / nc;
@@ -336,17 +340,22 @@ __global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __res
         if (ck::lane_id() == 0 && tl) atomicAdd(&blk[1], (uint32_t)tl);
     }
     if (ck::lane_id() == 0 && bad) atomicAdd(&blk[2], bad);
+    if (ck::ballot(sht != 0) != 0) {                        // (none for the headline batch)
+        const uint64_t ts = ck::wave_sum_u64(sht);
+        if (ck::lane_id() == 0) atomicAdd(&blk[3], (uint32_t)ts);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (blk[0]) atomicAdd(ctl, blk[0]);
         if (blk[1]) atomicAdd(ctl + 1, blk[1]);
         if (blk[2]) atomicAdd(ctl + 3, blk[2]);
+        if (blk[3]) atomicAdd(ctl + 5, blk[3]);
         // arrival ticket: the adds above are device-scope atomics (performed at the memory side, in order behind this
         // wave's earlier ones once drained), the last arriver reads the sums with atomics as well
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(ctl + 2, 1u) == gridDim.x - 1) {
-            const uint32_t t2 = atomicExch(ctl, 0u), tl = atomicExch(ctl + 1, 0u), tb = atomicExch(ctl + 3, 0u);
-            *mode = batch_mode_of(t2, tl, ns, tb, nc);
+            const uint32_t t2 = atomicExch(ctl, 0u), tl = atomicExch(ctl + 1, 0u), tb = atomicExch(ctl + 3, 0u), ts = atomicExch(ctl + 5, 0u);
+            *mode = batch_mode_of(t2, tl, ns, tb, nc, ts);
             atomicExch(ctl + 2, 0u);
         }
     }
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(1024) void stream_count_kernel(const uint8_t* __res
 // every kernel of a batch takes the mode from the same word (or the host's answer): bits 0..1 = stream_mode, MODE_ALPHA
 __device__ __forceinline__ uint32_t batch_mode(const uint32_t* __restrict__ mode, uint32_t host_mode)
 {
-    return host_mode ? host_mode & 7u : *mode;          // (bit 31: MODE_GUESS, see launch_canon)
+    return host_mode ? host_mode & 15u : *mode;         // (bit 31: MODE_GUESS, see launch_canon)
 }
 // Rescue pass (canon_stream.h): the streaming kernel's leftovers that are eligible by themselves, one wave per record.
 // A small persistent grid walks the list segments (a batch the streaming kernel handled completely leaves them
@@ -525,9 +534,10 @@ __global__ __launch_bounds__(StreamC::WPB * 64, (HASH && !AUX && StreamC::ROWS =
     if ((bm & 3) != (uint32_t)StreamC::ROWS) return;                             // the other build (or none) has this batch
     constexpr bool HAS_ALPHA_TWIN = StreamC::ROWS == 1 && !AUX;
     if (HAS_ALPHA_TWIN && ((bm & MODE_ALPHA) != 0) != ALPHA) return;
+    if (HAS_ALPHA_TWIN && !ALPHA && !HASH && ((bm & MODE_SHORT) != 0) != (StreamC::RPW == 2)) return;       // bytes only: the pair build has the batches of short records
     constexpr bool GH = CK_GROUP_HASH && HASH && !AUX && StreamC::ROWS == 1 && (StreamC::RPW == 1 || !ALPHA) && StreamC::GROUP <= 16;
     constexpr bool PAIR = GH && StreamC::RPW == 2;                                // canon_pair.h: two records per wave
-    constexpr bool PAIR_B = CK_STREAM_PAIR_BYTES && !HASH && !AUX && !ALPHA && StreamC::ROWS == 1 && StreamC::RPW == 2;    // (experiment: bytes only)
+    constexpr bool PAIR_B = !HASH && !AUX && !ALPHA && StreamC::ROWS == 1 && StreamC::RPW == 2;    // the bytes-only pair build: MODE_SHORT batches
     __shared__ __attribute__((aligned(16))) uint32_t lds[StreamC::LDS_DW + (GH ? ck::gh_lds_dw<(int)StreamC::GROUP, PAIR>() : PAIR_B ? StreamC::GROUP * ck::PAIR_SCRATCH_DW : 0)];
     uint32_t* lut = lds + StreamC::NBUF * StreamC::BUF_DW;
     uint32_t* blk_count = lut + ck::FAST_LUT_DW;
@@ -1275,7 +1285,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
     uint32_t guess_flag = 0;
     if (device_decides) {
         static const bool no_guess = getenv("CIRCKIT_NO_MODE_GUESS") != nullptr;
-        const uint32_t seen = *c->h_mode & 7u;
+        const uint32_t seen = *c->h_mode & 15u;
         if (!no_guess && (seen & 3u) && seen == c->mode_seen) { host_mode = seen; guess_flag = 0x80000000u; }
         c->mode_seen = seen;
         static const bool dbg = getenv("CIRCKIT_DEBUG_MODE_GUESS") != nullptr;
@@ -1383,7 +1393,21 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                 if (rows == 1) {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux, true, true, block_aux, false);
                     else if (d_hash) { if (alpha) CK_LAUNCH_STREAM(StreamCH, true, false, block_h, true); else CK_LAUNCH_STREAM(StreamCHP, true, false, block_hp, false); }
-                    else { if (alpha) CK_LAUNCH_STREAM(StreamCA, false, false, block_a, true); else if (CK_STREAM_PAIR_BYTES) CK_LAUNCH_STREAM(StreamCHP, false, false, block_hp, false); else CK_LAUNCH_STREAM(StreamC, false, false, block, false); }
+                    else if (alpha) CK_LAUNCH_STREAM(StreamCA, false, false, block_a, true);
+                    else {
+                        // bytes only, pure ACGT: one record per wave, or -- MODE_SHORT -- two; the host's answer launches one of the builds,
+                        // a device-side decision both (the one the previous batch did not use with the small grid)
+                        const bool expect_short = ((host_mode ? host_mode : seen) & MODE_SHORT) != 0;
+                        for (int sh = 0; sh < 2; ++sh) {
+                            if (host_mode && (sh != 0) != expect_short) continue;
+                            const bool full_sh = full && (sh != 0) == expect_short;
+                            const dim3 grid_sh(full_sh ? G : small);
+                            if (sh) { if (full_sh) hipLaunchKernelGGL((canon_stream_kernel<StreamCHP, false, false, false, false>), grid_sh, block_hp, 0, c->stream, a, counts, kmode, G);
+                                      else hipLaunchKernelGGL((canon_stream_kernel<StreamCHP, false, false, true, false>), grid_sh, block_hp, 0, c->stream, a, counts, kmode, G); }
+                            else { if (full_sh) hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false, false, false>), grid_sh, block, 0, c->stream, a, counts, kmode, G);
+                                   else hipLaunchKernelGGL((canon_stream_kernel<StreamC, false, false, true, false>), grid_sh, block, 0, c->stream, a, counts, kmode, G); }
+                        }
+                    }
                 } else {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux, false);
                     else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block, false);
@@ -1637,12 +1661,13 @@ int host_batch_enqueue(circkit_ctx* c, const uint8_t* bytes, const uint64_t* off
         fprintf(stderr, "  host_batch %-18s %.3f ms\n", what, std::chrono::duration<double>(now - dbg_t0).count() * 1e3);
         dbg_t0 = now;
     };
-    uint64_t two_word = 0, longer = 0, max_len = 0;   // the host has the offsets: it picks the streaming kernel's build
+    uint64_t two_word = 0, longer = 0, shorter = 0, max_len = 0;   // the host has the offsets: it picks the streaming kernel's build
     for (uint64_t i = 0; i < n; ++i) {
         if (offsets[i + 1] < offsets[i]) return fail(c, CIRCKIT_ERR_INVALID_ARG, "offsets decrease at record %llu", (unsigned long long)i);
         const uint64_t len = offsets[i + 1] - offsets[i];
         two_word += len > ck::FAST_MAX_N && len <= ck::FAST2_MAX_N;
         longer += len > ck::FAST2_MAX_N;
+        shorter += len <= SHORT_MAX_N;
         max_len = len > max_len ? len : max_len;
     }
     if (max_len >> 31) return fail(c, CIRCKIT_ERR_TOO_LONG, "a record of 2^31 symbols or more (cyclic positions are 32-bit)");
@@ -1759,7 +1784,7 @@ int host_batch_enqueue(circkit_ctx* c, const uint8_t* bytes, const uint64_t* off
             bad += b;
         }
     }
-    const uint32_t host_mode = batch_mode_of(two_word, longer, n, bad, nc);
+    const uint32_t host_mode = batch_mode_of(two_word, longer, n, bad, nc, shorter);
     dbg_lap("content sample");
     volatile uint32_t* unprocessed = c->h_mode + 4;                       // (pinned)
     for (int k = 0; k < parts; ++k) {

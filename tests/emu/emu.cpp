@@ -191,7 +191,7 @@ void stream_body(void* p)       // one fiber of a C::WPB-wave workgroup
         else ck::canon_stream_wave_loop<C, true, false, GHP>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);
     }
     else if (L->alpha && C::ROWS == 1) ck::canon_stream_wave_loop<C, false, false, false, C::ROWS == 1>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
-    else ck::canon_stream_wave_loop<C, false, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks);
+    else ck::canon_stream_wave_loop<C, false, false>(L->a, L->lut, L->lds, L->blk_count, L->block, L->nblocks, L->lds + C::LDS_DW);     // (two records per wave: the pair build's scratch)
 }
 // geometries the staged streaming kernel is exercised with (index = `staged` argument - 1)
 struct StreamVariant { void (*body)(void*); int wpb; uint32_t group, lds_dw; };

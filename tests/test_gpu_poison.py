@@ -28,7 +28,7 @@ ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 ref = None
 # Sizes that saturate the memory system: the guard's negative control (tools/poison_negative_control.py: the same build with
 # the waits REMOVED) counts ~1300 poisoned records at 8M x 1 kb -- and none at 200k, where every DMA lands in time anyway.
-for name, n, L, nfrac, outs in (("ROWS=1", 6_000_000, 1000, 0.0, "bytes"), ("ROWS=1 + XXH3 (pair build)", 6_000_000, 1000, 0.0, "hash"),
+for name, n, L, nfrac, outs in (("ROWS=1", 6_000_000, 1000, 0.0, "bytes"), ("ROWS=1 short records (bytes-only pair build)", 12_000_000, 400, 0.0, "bytes"), ("ROWS=1 + XXH3 (pair build)", 6_000_000, 1000, 0.0, "hash"),
                                 ("ROWS=1 XXH3 only (pair build, no stores)", 6_000_000, 1000, 0.0, "hashonly"), ("ROWS=1 + XXH3 ALPHA", 4_000_000, 1000, 0.01, "hash"), ("ROWS=1 ALPHA", 4_000_000, 1000, 0.01, "bytes"),
                                 ("ROWS=2", 3_000_000, 1500, 0.0, "bytes"), ("index/strand build", 3_000_000, 777, 0.0, "aux")):
     d_bytes, d_off = W.fixed_length(ctx, dev, n, L, 42, 0)

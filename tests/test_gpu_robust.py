@@ -186,7 +186,8 @@ def test_host_batch_page_locked_output(O, shift):
 def test_mode_guess_follows_the_data(O, want_hash):
     """launch_canon takes the mode the last device batches reported as the next batch's mode (only that mode's kernels are
     launched) once two launches in a row have read the same report.  Runs of batches of one kind with a change of kind
-    behind each run -- short records, mixed lengths, short records with N, 1.5 kb records -- so that every change meets a
+    behind each run -- short records, mixed lengths, short records with N, 1.5 kb records, records near 1 kb (the bytes-only build
+    for batches of short records against the one for the others) -- so that every change meets a
     WRONG guess first: the bytes (and hashes) are the oracle's all the same, and every batch reports its OWN mode."""
     import torch
     import circkit_amd
@@ -201,14 +202,15 @@ def test_mode_guess_follows_the_data(O, want_hash):
              (seqsets.random_mixed(302, n // 4, 200, 9000) + seqsets.random_mixed(303, n // 4, 2100, 20000), 3),
              (seqsets.random_mixed(304, n, 200, 1008, b"ACGTACGTACGTACGTACGTN"), 1),
              (seqsets.random_mixed(305, n, 1400, 1900), 2),
-             (seqsets.random_mixed(306, n // 4, 2500, 12000, b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTN"), 3)]
+             (seqsets.random_mixed(306, n // 4, 2500, 12000, b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTN"), 3),
+             (seqsets.random_mixed(307, n, 850, 1008), 1)]          # mode 1 like kind 0, but not MODE_SHORT: the other bytes-only build
     packed = []
     for seqs, mode in kinds:
         data, offs = seqsets.pack(seqs)
         exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
         packed.append((torch.from_numpy(np.concatenate([data, np.zeros(64, dtype=np.uint8)])).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev),
                        len(seqs), len(data), exp, exp_h, mode))
-    order = [0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 0, 4, 4, 4, 4, 1, 0]
+    order = [0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 0, 4, 4, 4, 4, 1, 0, 5, 5, 5, 5, 0, 0, 0, 5]
     for wait in (True, False):          # with a look at the device after every batch, and enqueued back to back
         outs = []
         for k in order:
