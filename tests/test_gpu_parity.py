@@ -735,11 +735,13 @@ def test_records_of_1009_to_2032_bases_two_words_per_lane(ctx, O):
     d_hash = torch.zeros(n, dtype=torch.int64, device=dev)
     for rep in range(3):                                            # 1st: small-grid fallback runs it; 2nd / 3rd: full grid
         d_out = torch.zeros_like(d_bytes)
-        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep else None)
+        ctx.canonicalize_batch_device(d_bytes, d_off, n, out_bytes=d_out, out_xxh3=d_hash if rep == 2 else None)
         torch.cuda.synchronize()
-        assert ctx.last_batch_mode() == 2
+        # (with the XXH3 a batch of two-word records is the mixed-length kernels': 8-11 % faster than the two-word build's
+        # per-record hash)
+        assert ctx.last_batch_mode() == (3 if rep == 2 else 2)
         assert np.array_equal(d_out.cpu().numpy(), exp), rep
-        if rep:
+        if rep == 2:
             assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
     # the two-word build has no alphabet twin: a batch of such records in which N is common (one record in sixteen or more) is the
     # mixed-length N kernels' (mode 3) -- left to the two-word build its N records went to LDS stage A one by one (6M x 1.5 kb with
