@@ -30,7 +30,7 @@ python tools/make_traffic.py $O/traffic.json \
   $O/r04_pmc_counters_canonicalize.txt "StreamCfg<16, 2, 1, 1>, false, false, false, false" "canonicalize 10000000 x 1000" 10000000 \
   $O/r04_pmc_counters_uniq.txt "StreamCfg<8, 2, 2, 1>, true, false, false, false" "uniq 10000000 x 1000" 10000000 \
   $O/r04_pmc_counters_mixed.txt "canon_mixed_kernel" "mixed 1000000 x 1000" 1000000 \
-  $O/r04_pmc_counters_canonicalize_n1pct.txt "StreamCfg<16, 2, 1, 1>, false, false, false, true" "canonicalize 10000000 x 1000 n0.01" 10000000 \
+  $O/r04_pmc_counters_canonicalize_n1pct.txt "StreamCfg<4, 2, 1, 1>, false, false, false, true" "canonicalize 10000000 x 1000 n0.01" 10000000 \
   $O/r04_pmc_counters_mixed_n1pct.txt "canon_mixed_n_kernel" "mixed 1000000 x 1000 n0.01" 1000000 \
   $O/r04_pmc_counters_mixed_uniq.txt "canon_mixed_h_kernel" "mixed 1000000 x 1000 hash" 1000000 \
   $O/r04_pmc_counters_uniq_hash_only.txt "StreamCfg<8, 2, 2, 1>, true, false, false, false" "uniq 10000000 x 1000 hash-only" 10000000 \
