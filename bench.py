@@ -613,6 +613,36 @@ def other_workloads(np, torch, circkit_amd, ctx, stream, dev, d_bytes, d_off, d_
     torch.cuda.synchronize()
     ctx.close()
     ctx = ctx_uniq
+    # ---- variants of the headline's shape (not BASELINE configs; round 4 found their slow corners): records of 300 b (the batch's
+    # bytes cut anew -- the bytes-only build for batches of short records), then 1 % N in the 1 kb records: canonicalize and uniq
+    del m_in, m_out, m_hash
+    ctx.synth_fill_device(42, 0, total, d_bytes)
+    table = U.DeviceTable(ctx)
+    L3 = 300
+    N3 = total // L3
+    d_off3 = torch.arange(N3 + 1, dtype=torch.int64, device=dev) * L3
+    ms = timed(lambda: ctx.canonicalize_batch_device(d_bytes, d_off3, N3, out_bytes=d_out))
+    ok = None
+    if check:
+        S3 = 20_000
+        e3, _ = O.canonicalize_batch(d_bytes[:S3 * L3].cpu().numpy(), np.arange(S3 + 1, dtype=np.uint64) * np.uint64(L3), True, False, threads=threads)
+        ok = bool(np.array_equal(d_out[:S3 * L3].cpu().numpy(), e3))
+    entry("canonicalize_300b", "canonicalize, %d x %d b (the headline batch's bytes cut into 300 b records)" % (N3, L3), ms, N3, 2 * N3 * L3 + 8 * N3, ok,
+          check="first 20000 records: canonical bytes vs the oracle")
+    del d_off3
+    W.sprinkle_n(d_bytes, total, 0.01, 46, dev)
+    if check:
+        exp, exp_h = O.canonicalize_batch(d_bytes[:S * L].cpu().numpy(), h_off, True, True, threads=threads)
+    ms = timed(lambda: ctx.canonicalize_batch_device(d_bytes, d_off, N, out_bytes=d_out))
+    entry("canonicalize_n1pct", "canonicalize, %d x %d b, 1 %% of the bases replaced by N" % (N, L), ms, N, 2 * total + 8 * N,
+          None if not check else bool(np.array_equal(d_out[:S * L].cpu().numpy(), exp)), check="first %d records: canonical bytes vs the oracle" % S)
+    d_hash = torch.empty(N, dtype=torch.int64, device=dev)
+    ms = timed(lambda: uniq_step(d_out))
+    table.check()
+    entry("uniq_n1pct", "uniq --canonicalize, %d x %d b, 1 %% of the bases replaced by N (no planted duplicates)" % (N, L), ms, N, 2 * total + 16 * N,
+          None if not check else bool(np.array_equal(d_out[:S * L].cpu().numpy(), exp)) and bool(np.array_equal(d_hash[:S].cpu().numpy(), exp_h.view(np.int64))),
+          unique_records=int(st["keep"].sum()), check="first %d records: canonical bytes + XXH3 vs the oracle" % S)
+    del d_hash
     res["note"] = ("same process and box as the headline, after its timed region and checks; one HIP stream; each entry = 2 warm-up + %d timed "
                    "steps of the whole kernel chain of that workload (HIP events on the launch stream); frac = algorithmic_bytes / time / 8 TB/s" % steps)
     return res
