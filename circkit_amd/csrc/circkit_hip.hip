@@ -577,6 +577,9 @@ __global__ __launch_bounds__(256) void xxh3_kernel(const uint8_t* bytes, const u
     const uint32_t wave = ck::uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t n_waves = gridDim.x * 4;
     const ck::XWaveConst xk = ck::xwave_const();
+    // (views: the complement table in LDS -- a reverse-strand view looks every byte up, and the short records' lanes each their own)
+    __shared__ uint8_t comp_lds[256];
+    if (view) { comp_lds[threadIdx.x] = comp[threadIdx.x]; __syncthreads(); comp = comp_lds; }
     if (!hashed) {
         for (uint64_t r = wave; r < n_records; r += n_waves) {
             const uint64_t off = offsets[r];
