@@ -233,7 +233,11 @@ __global__ __launch_bounds__(64) void xxh3_list_kernel(const uint8_t* bytes, con
 // are launched, the one the previous batch used with a full grid, the other with a small one -- until the batches before
 // have reported the same mode twice: then only that mode's build is launched (launch_canon, MODE_GUESS).
 using StreamC = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 1>;
-using StreamC2 = ck::StreamCfg<CK_STREAM_WPB, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
+// (the two-word build in 8-wave workgroups, four per CU: 9 GB batches of 1.2 / 1.5 / 2 kb records 5.11 / 4.50 / 3.82 -> 4.98 / 4.32 / 3.76 ms)
+#ifndef CK_STREAM_WPB_2
+#define CK_STREAM_WPB_2 8
+#endif
+using StreamC2 = ck::StreamCfg<CK_STREAM_WPB_2, CK_STREAM_NBUF, CK_STREAM_RPW, 2>;
 // The builds with the fused XXH3 (ROWS = 1) run 8-wave workgroups, four per CU, groups of 8 records (round 4): they are bound by
 // instruction issue, and four independent barrier domains per CU leave fewer issue slots empty than two -- hash only -3 % on
 // every box measured, bytes + hash -2 % .. 0.  The bytes-only builds are bound by the memory system and keep 16 waves (-1 % on one
@@ -1381,7 +1385,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const uint32_t seen = *c->h_mode;
         const uint32_t expect = host_mode ? host_mode & 3 : ((seen & 3) ? seen & 3 : 1u);
         const unsigned small = G < 2u * N_CU ? G : 2u * N_CU;
-        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64), block_h(StreamCH::WPB * 64), block_hp(StreamCHP::WPB * 64), block_a(StreamCA::WPB * 64);
+        const dim3 block(StreamC::WPB * 64), block_aux(StreamCAux::WPB * 64), block_h(StreamCH::WPB * 64), block_hp(StreamCHP::WPB * 64), block_a(StreamCA::WPB * 64), block_2(StreamC2::WPB * 64);
         // (rows, alphabet) builds: ROWS = 1 lean, ROWS = 1 with the 4-bit routine, ROWS = 2.  The host's answer launches
         // exactly one; a device-side decision launches all three, full-size where the previous batch's mode says it will run
         const uint32_t expect_alpha = host_mode ? host_mode & MODE_ALPHA : seen & MODE_ALPHA;
@@ -1416,8 +1420,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
                     }
                 } else {
                     if (aux) CK_LAUNCH_STREAM(StreamCAux2, true, true, block_aux, false);
-                    else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block, false);
-                    else CK_LAUNCH_STREAM(StreamC2, false, false, block, false);
+                    else if (d_hash) CK_LAUNCH_STREAM(StreamC2, true, false, block_2, false);
+                    else CK_LAUNCH_STREAM(StreamC2, false, false, block_2, false);
                 }
 #undef CK_LAUNCH_STREAM
             }

@@ -208,6 +208,8 @@ const StreamVariant kStream[] = {
     variant<ck::StreamCfg<4, 2, 2>>(), variant<ck::StreamCfg<8, 2, 2>>(),
     // the bytes-only N build's: 4 waves, one record each, two images
     variant<ck::StreamCfg<4, 2, 1>>(),
+    // the two-word build's: 8 waves, one record each, two images of 2 KiB per record
+    variant<ck::StreamCfg<8, 2, 1, 2>>(),
 };
 }
 

@@ -31,8 +31,8 @@ last_fused_hash_count = 0
 
 # `staged`: canon_stream.h's k-th workgroup geometry (WPB, RPW, NBUF), k >= 1; TWO_ROW = the ROWS == 2 builds
 STAGED_GEOMETRIES = {1: (16, 1, 2), 2: (8, 2, 3), 3: (4, 2, 2), 4: (8, 2, 2), 5: (2, 2, 4), 6: (1, 2, 3), 7: (4, 1, 4), 8: (8, 1, 6), 9: (4, 2, 4),
-                     10: (16, 1, 2), 11: (4, 2, 2), 12: (8, 1, 3), 13: (8, 1, 2), 14: (4, 2, 2), 15: (8, 2, 2), 16: (4, 1, 2)}       # 13: the hash build's geometry for batches with N, 14 / 15: the pair build's, 16: the bytes-only N build's (round 4)
-TWO_ROW = (10, 11, 12)
+                     10: (16, 1, 2), 11: (4, 2, 2), 12: (8, 1, 3), 13: (8, 1, 2), 14: (4, 2, 2), 15: (8, 2, 2), 16: (4, 1, 2), 17: (8, 1, 2)}       # 13: the hash build's geometry for batches with N, 14 / 15: the pair build's, 16: the bytes-only N build's (round 4)
+TWO_ROW = (10, 11, 12, 17)
 
 
 def alpha_rule(data, offsets):
