@@ -435,6 +435,17 @@ __global__ __launch_bounds__(256) void canon_rescue_kernel(ck::CanonArgs a, cons
 // 100 MHz wall clock, and the CU it ran on.
 __device__ uint64_t g_timeline[3 * 65536];
 #endif
+// Waves per workgroup of the mixed-length kernels (a slice of LDS each; a workgroup takes one list segment -- ~30 records of config 4 --
+// and leaves when its slowest wave does).  Measured on config 4, same box, 24 waves per CU in every case (tools/probe_variants.py):
+// bytes only 1 / 2 / 4 / 8 waves 1.90 / 1.88 / 1.81 / 1.75 ms, with the XXH3 2.17 / 2.11 / 2.20 / 2.52.  The N builds' resident grid
+// is sized for four.
+#ifndef CK_MIXED_WPB_PURE
+#define CK_MIXED_WPB_PURE 8
+#endif
+#ifndef CK_MIXED_WPB_HASH
+#define CK_MIXED_WPB_HASH 2
+#endif
+constexpr int mixed_wpb(bool nm, bool hash) { return nm ? 4 : (hash ? CK_MIXED_WPB_HASH : CK_MIXED_WPB_PURE); }
 template <bool NM, bool HASH>
 // Segments are handed out by a TICKET (round 4): a grid of as many workgroups as the chip holds at once, each taking the next
 // segment from a global counter until the segments run out -- no workgroup hand-over between segments (round 3's timeline of one
@@ -444,6 +455,7 @@ template <bool NM, bool HASH>
 __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const uint32_t* __restrict__ mode_word, uint32_t host_mode, uint32_t* mode_out, uint32_t* tiers_busy,
                                                  uint32_t* ticket)
 {
+    constexpr int WPB = mixed_wpb(NM, HASH);
     const uint32_t mode = batch_mode(mode_word, host_mode);
     if ((mode & 3) != 3 || ((mode & MODE_ALPHA) != 0) != NM) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = (host_mode >> 31) ? *mode_word : mode;
@@ -451,12 +463,12 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
     const uint64_t tl_start = wall_clock64();
 #endif
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t* blk_count = lds + 4 * a.slice_dw;
+    uint32_t* blk_count = lds + WPB * a.slice_dw;
     uint32_t* lut = blk_count + 4;
     uint32_t* lutn = lut + ck::FAST_LUT_DW;                // N builds: the 'G' / 'C' -> 'N' patch tables (the output is patched in registers)
     uint32_t* htab = lutn + ck::LEAN_LUTN_DW;              // (HASH builds: the XXH3 per-pair constants)
-    ck::fast_lut_init(lut, threadIdx.x, 256);
-    if (NM) ck::lean_lutn_init(lutn, threadIdx.x, 256);
+    ck::fast_lut_init(lut, threadIdx.x, 64 * WPB);
+    if (NM) ck::lean_lutn_init(lutn, threadIdx.x, 64 * WPB);
     if (HASH) ck::lean_hash_table_init(htab, threadIdx.x);
     ck::RescueState<HASH, false> st;
     if (HASH) {                                          // (only the lane's stripe secrets stay in registers: lean_hash_refill)
@@ -476,7 +488,7 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
         __syncthreads();
         const uint32_t sgm = blk_count[1];
         if (sgm >= a.in_nseg) break;                       // (every wave of every workgroup gets here: the segments run out)
-        ck::canon_mixed_segment<NM, HASH>(a, slice, lut, st, blk_count, sgm, wib, 4, payload_end, htab, lutn);
+        ck::canon_mixed_segment<NM, HASH>(a, slice, lut, st, blk_count, sgm, wib, WPB, payload_end, htab, lutn);
         __syncthreads();
         if (threadIdx.x == 0) { a.defer_count[sgm] = *blk_count; passed_on += *blk_count; ++walked; }
     }
@@ -505,12 +517,12 @@ __device__ __forceinline__ void canon_mixed_body(const ck::CanonArgs& a, const u
 #define CK_MIXED_N_SLICE 1904     // dwords per wave of the N builds: strand + N bits + candidates of a 20 kb record (1253 + 628 + 18); five workgroups per CU by LDS
 #endif
 #ifdef CK_MIXED_WAVES
-#define CK_MIXED_ATTR(VGPR) __launch_bounds__(256, CK_MIXED_WAVES)
+#define CK_MIXED_ATTR(VGPR, NM, HASH) __launch_bounds__(64 * mixed_wpb(NM, HASH), CK_MIXED_WAVES)
 #else
-#define CK_MIXED_ATTR(VGPR) __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(VGPR)))
+#define CK_MIXED_ATTR(VGPR, NM, HASH) __launch_bounds__(64 * mixed_wpb(NM, HASH)) __attribute__((amdgpu_num_vgpr(VGPR)))
 #endif
 #define CK_MIXED_KERNEL(NAME, NM, HASH, VGPR)                                                                                                  \
-    __global__ CK_MIXED_ATTR(VGPR) void NAME(ck::CanonArgs a, const uint32_t* __restrict__ mode_word,   \
+    __global__ CK_MIXED_ATTR(VGPR, NM, HASH) void NAME(ck::CanonArgs a, const uint32_t* __restrict__ mode_word,   \
                                                                                      uint32_t host_mode, uint32_t* mode_out, uint32_t* tiers_busy, uint32_t* ticket) \
     {                                                                                                                                          \
         canon_mixed_body<NM, HASH>(a, mode_word, host_mode, mode_out, tiers_busy, ticket);                                                     \
@@ -1474,13 +1486,14 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             // the N build keeps one N bit per symbol (and lean_resolve_n's candidates) behind the strand: half as much again, so
             // that a 20 kb record of config 4 fits a slice (n / 16 + n / 32 + 24 dwords) -- five workgroups = 20 waves per CU
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
-            const size_t shmem = (4 * a.slice_dw + 4 + ck::FAST_LUT_DW + ck::LEAN_LUTN_DW + (d_hash ? ck::LEAN_HASH_TABLE_DW : 0)) * 4;
+            const int mwpb = nm ? 4 : (d_hash ? mixed_wpb(false, true) : mixed_wpb(false, false));
+            const size_t shmem = ((size_t)mwpb * a.slice_dw + 4 + ck::FAST_LUT_DW + ck::LEAN_LUTN_DW + (d_hash ? ck::LEAN_HASH_TABLE_DW : 0)) * 4;
             if (d_hash) {
-                if (nm) hipLaunchKernelGGL(canon_mixed_nh_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
-                else hipLaunchKernelGGL(canon_mixed_h_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
+                if (nm) hipLaunchKernelGGL(canon_mixed_nh_kernel, dim3(grid), dim3(64 * mwpb), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
+                else hipLaunchKernelGGL(canon_mixed_h_kernel, dim3(grid), dim3(64 * mwpb), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
             } else {
-                if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
-                else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(256), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
+                if (nm) hipLaunchKernelGGL(canon_mixed_n_kernel, dim3(grid), dim3(64 * mwpb), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
+                else hipLaunchKernelGGL(canon_mixed_kernel, dim3(grid), dim3(64 * mwpb), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
             }
         }
     }
