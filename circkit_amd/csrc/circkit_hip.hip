@@ -445,7 +445,10 @@ __device__ uint64_t g_timeline[3 * 65536];
 #ifndef CK_MIXED_WPB_HASH
 #define CK_MIXED_WPB_HASH 2
 #endif
-constexpr int mixed_wpb(bool nm, bool hash) { return nm ? 4 : (hash ? CK_MIXED_WPB_HASH : CK_MIXED_WPB_PURE); }
+#ifndef CK_MIXED_WPB_N
+#define CK_MIXED_WPB_N 4
+#endif
+constexpr int mixed_wpb(bool nm, bool hash) { return nm ? CK_MIXED_WPB_N : (hash ? CK_MIXED_WPB_HASH : CK_MIXED_WPB_PURE); }
 template <bool NM, bool HASH>
 // Segments are handed out by a TICKET (round 4): a grid of as many workgroups as the chip holds at once, each taking the next
 // segment from a global counter until the segments run out -- no workgroup hand-over between segments (round 3's timeline of one
@@ -1479,14 +1482,14 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             if (host_mode && ((host_mode & MODE_ALPHA) != 0) != (nm != 0)) continue;
             const bool expected = host_mode ? true : ((seen & 3) == 3 && ((seen & MODE_ALPHA) != 0) == (nm != 0));
             // N builds: a resident grid (five workgroups per CU) fed by ticket; pure builds: one workgroup per segment
-            const unsigned resident = (unsigned)N_CU * 5u;
+            const unsigned resident = (unsigned)N_CU * (20u / (unsigned)mixed_wpb(true, false));      // (20 waves per CU by LDS)
             const unsigned full = nm ? (nseg < resident ? nseg : resident) : nseg;
             const unsigned grid = expected ? full : walking;
             uint32_t* ticket = nm ? c->d_counters + 16 : nullptr;   // [16], [17]: self-zeroing
             // the N build keeps one N bit per symbol (and lean_resolve_n's candidates) behind the strand: half as much again, so
             // that a 20 kb record of config 4 fits a slice (n / 16 + n / 32 + 24 dwords) -- five workgroups = 20 waves per CU
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
-            const int mwpb = nm ? 4 : (d_hash ? mixed_wpb(false, true) : mixed_wpb(false, false));
+            const int mwpb = nm ? mixed_wpb(true, d_hash != nullptr) : (d_hash ? mixed_wpb(false, true) : mixed_wpb(false, false));
             const size_t shmem = ((size_t)mwpb * a.slice_dw + 4 + ck::FAST_LUT_DW + ck::LEAN_LUTN_DW + (d_hash ? ck::LEAN_HASH_TABLE_DW : 0)) * 4;
             if (d_hash) {
                 if (nm) hipLaunchKernelGGL(canon_mixed_nh_kernel, dim3(grid), dim3(64 * mwpb), shmem, c->stream, a, counts, kmode, mode_out, c->d_counters + 1, ticket);
