@@ -1483,9 +1483,17 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
             const bool expected = host_mode ? true : ((seen & 3) == 3 && ((seen & MODE_ALPHA) != 0) == (nm != 0));
             // N builds: a resident grid (five workgroups per CU) fed by ticket; pure builds: one workgroup per segment
             const unsigned resident = (unsigned)N_CU * (20u / (unsigned)mixed_wpb(true, false));      // (20 waves per CU by LDS)
+#ifdef CK_MIXED_N_STATIC
+            const unsigned full = nseg;                    // EXPERIMENT: the N builds on the static mapping too
+#else
             const unsigned full = nm ? (nseg < resident ? nseg : resident) : nseg;
+#endif
             const unsigned grid = expected ? full : walking;
+#ifdef CK_MIXED_N_STATIC
+            uint32_t* ticket = nullptr;
+#else
             uint32_t* ticket = nm ? c->d_counters + 16 : nullptr;   // [16], [17]: self-zeroing
+#endif
             // the N build keeps one N bit per symbol (and lean_resolve_n's candidates) behind the strand: half as much again, so
             // that a 20 kb record of config 4 fits a slice (n / 16 + n / 32 + 24 dwords) -- five workgroups = 20 waves per CU
             a.slice_dw = nm ? CK_MIXED_N_SLICE : TIER_DW[0];
