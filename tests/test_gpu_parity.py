@@ -883,3 +883,32 @@ def test_low_complexity_records_in_a_mixed_length_batch(ctx, O, with_n):
         if want_hash:
             assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
     ctx.use_own_stream()
+
+
+def test_batches_of_short_records_bytes_only_pair_build(ctx, O):
+    """MODE_SHORT (end of round 4): a batch whose records are mostly <= 800 symbols runs the bytes-only PAIR build of the streaming
+    kernel (canon_pair.h: two records per wave) -- decided on the device from the count kernel's samples, guessed from the third
+    batch on.  Lengths 48..600 with everything the routine refuses mixed in (shorter, N, gaps, periodic, palindromes), fixed
+    lengths 100 / 200 / 300 / 500, and a batch of records near 1 kb behind them (the other build, after a wrong guess)."""
+    import torch
+    from tests import seqsets
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    batches = [seqsets.random_mixed(901, 20000, 48, 600) + seqsets.random_mixed(902, 300, 1, 47) + seqsets.random_mixed(903, 300, 48, 600, b"ACGTN-") +
+               seqsets.adversarial()[:200]]
+    for L in (100, 200, 300, 500):
+        batches.append(seqsets.random_mixed(910 + L, 6000, L, L))
+    batches.append(seqsets.random_mixed(905, 6000, 900, 1008))
+    batches.append(batches[0])
+    for seqs in batches:
+        data, offs = seqsets.pack(seqs)
+        exp, _ = O.canonicalize_batch(data, offs, True, False, threads=8)
+        d_bytes = torch.from_numpy(np.concatenate([data, np.zeros(64, dtype=np.uint8)])).to(dev)
+        d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+        for rep in range(3):
+            d_out = torch.zeros_like(d_bytes)
+            ctx.canonicalize_batch_device(d_bytes, d_off, len(seqs), out_bytes=d_out)
+            torch.cuda.synchronize()
+            assert ctx.batch_status() == 0 and ctx.last_batch_mode() == 1
+            assert np.array_equal(d_out[:len(data)].cpu().numpy(), exp), (len(seqs), rep)
+    ctx.use_own_stream()
