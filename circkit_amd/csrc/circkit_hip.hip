@@ -46,21 +46,27 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
     uint32_t* blk_count = lds + WPB * a.slice_dw;
     uint32_t* lut = blk_count + 4;                   // 2-bit decode table shared by the workgroup's waves
     uint32_t* lutn = lut + ck::FAST_LUT_DW;          // ...and the 'G' -> 'N' patch table of the 2-bit-with-N-mask mode
+    uint32_t live = ~0u;      // bit j: this workgroup's j-th virtual workgroup has input (those from the 32nd on are walked unseen)
     if (a.list && gridDim.x < nvb) {
         // walking grid (the previous batch left the tiers next to nothing): one parallel look at this workgroup's input
         // segments; if all are empty, zero the output counts and leave -- walking them one dependent load and two barriers
-        // at a time made the five idle tiers ~80 us of every batch (headline 3.74 -> 3.70 ms, same box)
+        // at a time made the five idle tiers ~80 us of every batch (headline 3.74 -> 3.70 ms, same box).  If a few are not
+        // (the leftovers of a mixed-length batch with N: 244 records in 32768 segments), only those are walked: stage A of
+        // that batch 77 -> 70 us (what remains is its longest record in the 4-bit mode, one wave)
         const uint32_t per = a.segs_per_block, mine = (nvb - blockIdx.x + gridDim.x - 1) / gridDim.x;
+        if (threadIdx.x == 0) blk_count[1] = 0;
+        __syncthreads();
         uint32_t any = 0;
         for (uint32_t t = threadIdx.x; t < mine * per; t += WPB * 64) {
-            const uint32_t sgm = (blockIdx.x + (t / per) * gridDim.x) * per + t % per;
-            if (sgm < a.in_nseg) any |= a.list_count[sgm];
+            const uint32_t j = t / per, sgm = (blockIdx.x + j * gridDim.x) * per + t % per;
+            if (sgm < a.in_nseg && a.list_count[sgm]) { any = 1; if (j < 32) atomicOr(blk_count + 1, 1u << j); }
         }
         if (!__syncthreads_or((int)any)) {
             if (a.defer_count)
                 for (uint32_t t = threadIdx.x; t < mine; t += WPB * 64) a.defer_count[blockIdx.x + t * gridDim.x] = 0;
             return;
         }
+        live = ck::uniform(blk_count[1]);            // (the team pass's use of this word is behind the loop's first barrier)
     }
     ck::fast_lut_init(lut, threadIdx.x, WPB * 64);
     ck::fast_lutn_init(lutn, threadIdx.x, WPB * 64);
@@ -68,7 +74,11 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
     // `nvb` virtual workgroups (one output segment each) walked by a grid that is no bigger than what keeps the chip
     // busy: on the batches where these tiers have nothing to do (the headline) one workgroup per segment was 12-28 us of
     // pure dispatch per tier
-    for (uint32_t vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    for (uint32_t vb = blockIdx.x, j = 0; vb < nvb; vb += gridDim.x, ++j) {
+        if (j < 32 && !((live >> j) & 1u)) {
+            if (threadIdx.x == 0 && a.defer_count) a.defer_count[vb] = 0;
+            continue;
+        }
         if (threadIdx.x == 0) *blk_count = 0;
         __syncthreads();
         ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, vb, nvb, wib, WPB, lutn);
