@@ -804,28 +804,32 @@ CK_DEV int canon_record_mode2n(const CanonArgs& a, uint64_t rec, const uint8_t* 
 // record untouched for the tiers behind.  Every wave of the workgroup runs through the same barriers: all decisions are
 // taken on values read back from LDS.
 // ------------------------------------------------------------------------------------------------
-CK_DEV void build_extension2(uint32_t* Ef, uint32_t n)      // lanes 0..2 of one wave, the strand complete and visible
+template <int BITS>
+CK_DEV void build_extension(uint32_t* Ef, uint32_t n)      // lanes 0..2 of one wave, the strand complete and visible
 {
-    const uint32_t lane = lane_id(), nwf = n >> 4, r = n & 15, nwv = nwf + (r ? 1u : 0u);
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t lane = lane_id(), nwf = n / S, r = n % S, nwv = nwf + (r ? 1u : 0u);
     if (lane == 0) {
-        if (r) Ef[nwf] = Ef[nwf] | (Ef[0] >> (r * 2));
+        if (r) Ef[nwf] = Ef[nwf] | (Ef[0] >> (r * BITS));
     } else if (lane < 3) {
         const uint32_t e = lane - 1;
-        Ef[nwv + e] = r ? funnel(Ef[e], Ef[e + 1], (16 - r) * 2) : Ef[e];
+        Ef[nwv + e] = r ? funnel(Ef[e], Ef[e + 1], (S - r) * BITS) : Ef[e];
     }
 }
+CK_DEV void build_extension2(uint32_t* Ef, uint32_t n) { build_extension<2>(Ef, n); }
 // one strand: minimal key M, how many valid positions own it, the smallest of them -- and what this lane knows about the
 // owners (team_settle)
 struct TeamOwn { uint32_t M, owners, pos, lane_word, lane_mask; };
-template <bool RCV>
+template <int BITS, bool RCV>
 CK_DEV TeamOwn team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, uint32_t team, uint32_t* comm)
 {
-    const uint32_t lane = lane_id(), nwv = (n + 15) / 16;
+    constexpr uint32_t S = 32 / BITS;
+    const uint32_t lane = lane_id(), nwv = (n + S - 1) / S;
     if (member == 0 && lane == 0) { comm[0] = ~0u; comm[1] = 0; comm[2] = ~0u; }
     block_barrier();
     uint32_t best = ~0u, bestw = 0, ties = 0;
     for (uint32_t w = member * 64 + lane; w < nwv; w += team * 64) {
-        const uint32_t m = word_min_key<2>(view_word<2, RCV>(E, w * 16, n), view_word<2, RCV>(E, (w + 1) * 16, n));
+        const uint32_t m = word_min_key<BITS>(view_word<BITS, RCV>(E, w * S, n), view_word<BITS, RCV>(E, (w + 1) * S, n));
         if (m < best || ties == 0) { best = m; bestw = w; ties = 1; }
         else if (m == best) ++ties;
     }
@@ -839,12 +843,12 @@ CK_DEV TeamOwn team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, 
         if (ties > 1) {
             cnt = 64;                                           // several of this lane's words hold M: more than the team settles
         } else {
-            uint32_t mask = word_eq_mask<2>(view_word<2, RCV>(E, bestw * 16, n), view_word<2, RCV>(E, (bestw + 1) * 16, n), r.M);
-            const uint32_t valid = n - bestw * 16;
-            if (valid < 16) mask &= (1u << valid) - 1u;         // the last word's positions behind the record end repeat word 0's
+            uint32_t mask = word_eq_mask<BITS>(view_word<BITS, RCV>(E, bestw * S, n), view_word<BITS, RCV>(E, (bestw + 1) * S, n), r.M);
+            const uint32_t valid = n - bestw * S;
+            if (valid < S) mask &= (1u << valid) - 1u;          // the last word's positions behind the record end repeat word 0's
             r.lane_mask = mask;
             cnt = (uint32_t)popc32(mask);
-            if (mask) p = bestw * 16 + (uint32_t)ffs32(mask);
+            if (mask) p = bestw * S + (uint32_t)ffs32(mask);
         }
     }
     const uint32_t cw = (uint32_t)wave_sum_u64(cnt), pw = wave_min_u32(p);
@@ -860,25 +864,26 @@ CK_DEV TeamOwn team_scan_locate(const uint32_t* E, uint32_t n, uint32_t member, 
 // and the smallest rotation kept (lcp_rot: every wave computes the same).  false: too many owners, or two equal rotations
 // (a period): the general routine's.
 constexpr uint32_t TEAM_MAX_OWNERS = 8;
-template <bool RCV>
+template <int BITS, bool RCV>
 CK_DEV bool team_settle(const uint32_t* E, uint32_t n, uint32_t member, uint32_t* comm, TeamOwn& o)
 {
+    constexpr uint32_t S = 32 / BITS;
     if (o.owners == 1) return true;
     if (o.owners > TEAM_MAX_OWNERS) return false;
-    const uint32_t lane = lane_id(), base = o.lane_word * 16;
+    const uint32_t lane = lane_id(), base = o.lane_word * S;
     uint32_t best = o.pos, last = o.pos;
     for (uint32_t k = 1; k < o.owners; ++k) {
         if (member == 0 && lane == 0) comm[2] = ~0u;
         block_barrier();
         uint32_t m = o.lane_mask;                               // this lane's owners behind `last`
-        if (m && last >= base) m = last - base >= 15 ? 0u : m & ~((2u << (last - base)) - 1u);
+        if (m && last >= base) m = last - base >= S - 1 ? 0u : m & ~((2u << (last - base)) - 1u);
         const uint32_t pw = wave_min_u32(m ? base + (uint32_t)ffs32(m) : ~0u);
         if (lane == 0 && pw != ~0u) lds_atomic_min(comm + 2, pw);
         block_barrier();
         const uint32_t nxt = comm[2];
         block_barrier();
         if (nxt == ~0u) return false;
-        const Lcp c = lcp_rot<2, RCV, RCV>(E, E, best, nxt, n);
+        const Lcp c = lcp_rot<BITS, RCV, RCV>(E, E, best, nxt, n);
         if (c.k >= n) return false;
         if (c.cmp > 0) best = nxt;
         last = nxt;
@@ -887,42 +892,47 @@ CK_DEV bool team_settle(const uint32_t* E, uint32_t n, uint32_t member, uint32_t
     return true;
 }
 // lds: the workgroup's slices (team * slice_dw dwords); comm: three LDS words
-// returns 0: done; 1: a byte outside ACGT; 2: a tie / equal strands (the general routine's business)
-CK_DEV int canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, uint32_t* comm, uint32_t member, uint32_t team)
+// returns 0: done; 1: a byte outside the mode's alphabet (ACGT; BITS = 4: -ACGNT); 2: a tie / equal strands (the general routine's business)
+// BITS = 4 (round 4): the same team for what the 2-bit modes refuse -- an N inside the winning window behind a prefix other
+// windows share, gaps -- with 8-symbol keys (so: more often a few owners of the minimal key, team_settle's); before it such a
+// record beyond a slice was wave 0's alone (a batch of 40 000 records of 20..80 kb with 1 % N: 3.28 -> 2.13 ms)
+template <int BITS>
+CK_DEV int canon_record_team(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, uint32_t* comm, uint32_t member, uint32_t team)
 {
+    constexpr uint32_t S = 32 / BITS;
     const uint64_t off = a.offsets[rec];
-    const uint32_t n = (uint32_t)(a.offsets[rec + 1] - off), nwv = (n + 15) / 16, lane = lane_id();
+    const uint32_t n = (uint32_t)(a.offsets[rec + 1] - off), nwv = (n + S - 1) / S, lane = lane_id();
     const uint8_t* src = a.bytes + off;
     uint32_t* E = lds;
     if (member == 0 && lane == 0) comm[0] = 0;
     block_barrier();
-    if (!build_packed<2>(src, n, E, E, member, team) && lane == 0) lds_atomic_or(comm, 1u);
+    if (!build_packed<BITS>(src, n, E, E, member, team) && lane == 0) lds_atomic_or(comm, 1u);
     block_barrier();
     const bool not_acgt = comm[0] != 0;
-    if (member == 0) build_extension2(E, n);
+    if (member == 0) build_extension<BITS>(E, n);
     block_barrier();                                            // (also: comm[0] has been read by everybody)
     if (not_acgt) return 1;
     const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
-    TeamOwn F = team_scan_locate<false>(E, n, member, team, comm), C = F;
-    if (!fwd_only) C = team_scan_locate<true>(E, n, member, team, comm);
+    TeamOwn F = team_scan_locate<BITS, false>(E, n, member, team, comm), C = F;
+    if (!fwd_only) C = team_scan_locate<BITS, true>(E, n, member, team, comm);
     // lib/src/canonicalize.rs:58-62: forward only if strictly smaller.  Equal minimal keys: the two rotations are compared
     // in full; a minimal key with a few owners: the smallest of their rotations.  More owners, periods: the general routine.
     bool fwd = fwd_only || F.M < C.M;
     if (!fwd_only && F.M == C.M) {
-        if (!team_settle<false>(E, n, member, comm, F) || !team_settle<true>(E, n, member, comm, C)) return 2;
-        fwd = lcp_rot<2, false, true>(E, E, F.pos, C.pos, n).cmp < 0;
+        if (!team_settle<BITS, false>(E, n, member, comm, F) || !team_settle<BITS, true>(E, n, member, comm, C)) return 2;
+        fwd = lcp_rot<BITS, false, true>(E, E, F.pos, C.pos, n).cmp < 0;
     } else {
-        if (!(fwd ? team_settle<false>(E, n, member, comm, F) : team_settle<true>(E, n, member, comm, C))) return 2;
-        if (!fwd && a.out_index && !team_settle<false>(E, n, member, comm, F)) return 2;     // the reference-visible index counts from the forward minimum
+        if (!(fwd ? team_settle<BITS, false>(E, n, member, comm, F) : team_settle<BITS, true>(E, n, member, comm, C))) return 2;
+        if (!fwd && a.out_index && !team_settle<BITS, false>(E, n, member, comm, F)) return 2;     // the reference-visible index counts from the forward minimum
     }
     const uint32_t pF = F.pos, pC = C.pos;
     const uint32_t idx = fwd ? pF : pC;
     if (a.out_bytes) {
         uint8_t* out = a.out_bytes + off;
         for (uint32_t w = member * 64 + lane; w < nwv; w += team * 64) {
-            const u32x4 o = fwd ? decode_word<2, false>(E, idx + w * 16, n, lut) : decode_word<2, true>(E, idx + w * 16, n, lut);
-            const uint32_t left = n - w * 16;
-            store_bytes(out + w * 16, o, left < 16 ? left : 16);
+            const u32x4 o = fwd ? decode_word<BITS, false>(E, idx + w * S, n, lut) : decode_word<BITS, true>(E, idx + w * S, n, lut);
+            const uint32_t left = n - w * S;
+            store_bytes(out + w * S, o, left < S ? left : S);
         }
     }
     if (member == 0 && lane == 0) {
@@ -932,6 +942,16 @@ CK_DEV int canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, c
     }
     block_barrier();                                            // the strand is read to the end before the next record's build
     return 0;
+}
+CK_DEV int canon_record_team2(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, uint32_t* comm, uint32_t member, uint32_t team)
+{
+    return canon_record_team<2>(a, rec, lds, lut, comm, member, team);
+}
+// (As a call of its own -- __noinline__, arguments by value -- the 4-bit team took the tier kernel around it from 72 to 87
+// vector registers; inlined it costs that kernel five spilled registers on its own path.)
+CK_DEV int canon_record_team4(const CanonArgs& a, uint64_t rec, uint32_t* lds, uint32_t* comm, uint32_t member, uint32_t team)
+{
+    return canon_record_team<4>(a, rec, lds, nullptr, comm, member, team);
 }
 // a record the team takes: too long for one wave's slice, short enough for all of them together
 CK_DEV bool team_takes(uint32_t n, uint32_t slice_dw, uint32_t team) { return need_dw_strand2(n) > slice_dw && need_dw_strand2(n) <= team * slice_dw; }
@@ -960,9 +980,9 @@ CK_DEV bool canon_record_team2n(const CanonArgs& a, uint64_t rec, uint32_t* lds,
         return (uint32_t)(s0 + ((s0 >> 31) & (int32_t)n));
     };
     const bool fwd_only = (a.flags & CK_FLAG_FWD_ONLY) != 0;
-    const TeamOwn F = team_scan_locate<false>(E, n, member, team, comm);
+    const TeamOwn F = team_scan_locate<2, false>(E, n, member, team, comm);
     TeamOwn C = F;
-    if (!fwd_only) C = team_scan_locate<true>(E, n, member, team, comm);
+    if (!fwd_only) C = team_scan_locate<2, true>(E, n, member, team, comm);
     const uint32_t MF = F.M, oF = F.owners, pF = F.pos, MC = fwd_only ? ~0u : C.M, oC = fwd_only ? 1u : C.owners, pC = C.pos;
     if (!fwd_only && MF == MC) return false;
     const bool fwd = fwd_only || MF < MC;
@@ -1007,6 +1027,9 @@ CK_DEV bool canon_record_team2n(const CanonArgs& a, uint64_t rec, uint32_t* lds,
     return true;
 }
 CK_DEV bool team_takes_2n(uint32_t n, uint32_t slice_dw, uint32_t team) { return n >= 48 && need_dw_2n(n) > slice_dw && need_dw_2n(n) <= team * slice_dw; }
+// ...and what is left for the 4-bit team (the one-wave 4-bit mode did not fit its slice: strand + candidate bitmask): the strand alone
+CK_DEV uint32_t need_dw_strand4(uint32_t n) { return (n + 7) / 8 + 2; }
+CK_DEV bool team_takes_4(uint32_t n, uint32_t slice_dw, uint32_t team) { return n >= 48 && need_dw_strand4(n) <= team * slice_dw; }
 
 // List entries: bits 0..30 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
 // that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte).
@@ -1099,7 +1122,7 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
 // entries the team can take (team_takes, pure ACGT as far as anybody knows) are canonicalized by all waves together and
 // leave the segment, the others move up.  blk_count[0] = entries, blk_count[1..3] = the team's three words.
 CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, uint32_t* blk_count, uint32_t block, uint32_t wib, uint32_t wpb,
-                      bool allow_solo = true)
+                      bool allow_solo = true, bool team4 = true)
 {
     const uint32_t cnt = *blk_count;
     if (cnt == 0 || !a.defer_list) return;
@@ -1115,6 +1138,8 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, co
             int why = (entry & ENTRY_NOT_ACGT) ? 1 : 3;            // 3: not tried
             if (why == 3 && team_takes((uint32_t)len, a.slice_dw, wpb)) { why = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb); done = why == 0; }
             if (why == 1 && lutn && team_takes_2n((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, wpb);
+            // what the N-mask team refuses (an N in the winning window behind a shared prefix), gaps: the 4-bit team
+            if (team4 && !done && why == 1 && lutn && team_takes_4((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team4(a, rec, lds, blk_count + 1, wib, wpb) == 0;
         }
         if (!done && lutn && allow_solo) {
             // not the team's (4-bit and byte modes, periods): wave 0 alone with the workgroup's whole LDS, the general

@@ -39,7 +39,12 @@ namespace {
 #ifndef CK_TIER_WPE
 #define CK_TIER_WPE 7      // min waves per SIMD the LDS-tier kernels are compiled for: 72 VGPRs, no spills (measured: 1 -> 76 VGPRs / 6 waves +2.7 %, 8 -> spills +1.2 %)
 #endif
-template <int WPB>
+// T4: with the 4-bit team in the team pass.  Inlined it costs this kernel five spilled vector registers -- on its own path, but
+// a kernel with a scratch allocation is ~5 us slower to dispatch, twice in EVERY batch (stages A and C; measured on config 4
+// + 1 % N: 2.068 -> 2.078 ms); as a __noinline__ call it takes the kernel from 72 to 87 registers.  So two builds: the one
+// without it for batches whose predecessor left the tiers next to nothing (launch_canon's tiers_idle; their few long records
+// with an N in the winning window go to wave 0 alone, as before round 4), the one with it for tiers that have real work.
+template <int WPB, bool T4 = false>
 __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonArgs a, uint32_t nvb, uint32_t* giants)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -83,7 +88,7 @@ __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonA
         __syncthreads();
         ck::canon_wave_loop(a, lds + wib * a.slice_dw, lut, blk_count, vb, nvb, wib, WPB, lutn);
         __syncthreads();
-        if (WPB > 1) ck::team_pass(a, lds, lut, lutn, blk_count, vb, wib, WPB);      // records too long for one wave's slice: all waves together
+        if (WPB > 1) ck::team_pass(a, lds, lut, lutn, blk_count, vb, wib, WPB, true, T4);      // records too long for one wave's slice: all waves together
         if (threadIdx.x == 0 && a.defer_count) a.defer_count[vb] = *blk_count;
         if (threadIdx.x == 0 && giants && *blk_count) atomicAdd(giants, *blk_count);     // last LDS tier: tell the global-scratch kernel there is work
     }
@@ -115,6 +120,7 @@ __device__ __forceinline__ void team_stage_block(const ck::CanonArgs& a, uint32_
                 int why = (entry & ck::ENTRY_NOT_ACGT) ? 1 : 3;
                 if (why == 3 && ck::need_dw_strand2(n) <= total_dw) { why = ck::canon_record_team2(a, rec, buf, lut, blk_count + 1, wib, TEAM_WAVES); done = why == 0; }
                 if (why == 1 && ck::need_dw_2n(n) <= total_dw) done = ck::canon_record_team2n(a, rec, buf, lut, lutn, blk_count + 1, wib, TEAM_WAVES);
+                if (!done && why == 1 && ck::need_dw_strand4(n) <= total_dw) done = ck::canon_record_team4(a, rec, buf, blk_count + 1, wib, TEAM_WAVES) == 0;
             }
             if (!done) {
                 // not the team's: wave 0 alone with the same buffer, the general routine; the others wait
@@ -1569,7 +1575,8 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
         const unsigned bpc = tiers_idle ? CK_TIER_BPC_IDLE : CK_TIER_BPC;
         const unsigned launched = grid < (unsigned)N_CU * bpc ? grid : (unsigned)N_CU * bpc;
         if (last) hipLaunchKernelGGL(canon_team_kernel, dim3(launched), dim3(TEAM_WAVES * 64), (TEAM_WAVES * TEAM_SLICE_DW + TIER_EXTRA_DW) * 4, c->stream, a, grid, c->d_counters);
-        else hipLaunchKernelGGL(canon_kernel<4>, dim3(launched), dim3(256), (4 * a.slice_dw + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
+        else if (tiers_idle) hipLaunchKernelGGL((canon_kernel<4, false>), dim3(launched), dim3(256), (4 * a.slice_dw + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
+        else hipLaunchKernelGGL((canon_kernel<4, true>), dim3(launched), dim3(256), (4 * a.slice_dw + TIER_EXTRA_DW) * 4, c->stream, a, grid, (uint32_t*)nullptr);
         nseg = grid;
         seg_cap = spb * seg_cap;
     }

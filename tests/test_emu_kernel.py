@@ -464,6 +464,58 @@ def test_team_mode_with_n_bitmask():
     assert done >= len(seqs) // 2 and kept_with_n_in_window >= 3, (done, len(seqs), kept_with_n_in_window)
 
 
+def test_team_mode_four_bit():
+    """The 4-bit team (round 4): what the 2-bit teams refuse -- gaps, an N inside the winning window behind a prefix that other
+    windows share -- and the one-wave 4-bit mode has no room for (slice of 120 dwords: strand + candidate bitmask of ~750
+    symbols; the four slices together hold a 4-bit strand of ~3.8 kb).  Without the wave-0-alone fallback (solo=False) a record
+    with a gap can only have been done by this team.  Lengths around the row (512 symbols) and word (8) boundaries, both strands,
+    a minimal 8-mer with a few owners (team_settle), rotation index and strand as the reference sees them."""
+    rng = np.random.default_rng(1700)
+    comp = bytes.maketrans(b"ACGTN-", b"TGCAN-")
+    seqs = []
+    for L in [760, 800, 1023, 1024, 1025, 1031, 1032, 1033, 1536, 2047, 2048, 2049, 3000, 3583, 3584, 3585, 3800, 3816]:
+        s = bytearray(seqsets.random_mixed(1701 + L, 1, L, L)[0])
+        for p in rng.integers(0, L, size=max(1, L // 200)):
+            s[int(p)] = ord("-") if rng.random() < 0.5 else ord("N")
+        s[int(rng.integers(0, L))] = ord("-")                    # at least one gap: never 2-bit material
+        seqs.append(bytes(s))
+    n_gap = len(seqs)
+    for case in range(60):                                       # the planted near-ties of the prefix rule: 2n team or this one
+        L = int(rng.integers(800, 3800))
+        bg = bytearray(rng.choice(list(b"CGT"), size=L, p=[0.2, 0.4, 0.4]).astype(np.uint8).tobytes())
+        run = int(rng.integers(2, 8))
+        for sp in sorted(rng.choice(np.arange(20, L - 40, 30), size=int(rng.integers(2, 5)), replace=False)):
+            motif = b"A" * run + bytes(rng.choice(list(b"NGTCN"), size=1).astype(np.uint8)) + bytes(rng.choice(list(b"ACGT"), size=6).astype(np.uint8))
+            if rng.random() < 0.5:
+                motif = motif.translate(comp)[::-1]
+            bg[sp:sp + len(motif)] = motif
+        seqs.append(bytes(bg))
+    data, offs = seqsets.pack(seqs)
+    want = [seqsets.expected(O, s) for s in seqs]
+    out, idx, strand, h, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False,
+                                                               solo=False)
+    assert status == 0
+    done_gap = done = 0
+    strands = set()
+    for i, s in enumerate(seqs):
+        if strand[i] == 0xFF:
+            continue
+        done += 1
+        done_gap += i < n_gap
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out[a:b].tobytes() == want[i][0], (i, len(s))
+        assert (int(strand[i]), int(idx[i])) == (want[i][1], want[i][2]), (i, len(s))
+        strands.add(int(strand[i]))
+    # (a tie of the minimal 8-mer beyond what the team settles -- a period, more than eight owners -- stays for wave 0 alone)
+    assert done_gap == n_gap and done >= len(seqs) - 2 and strands == {0, 1}, (done_gap, n_gap, done, len(seqs))
+    # with the fallback: everything, same answers
+    out2, idx2, strand2, _, status, ndef = emu.canonicalize_batch(data, offs, want_hash=False, want_aux=True, staged=0, slice_dw=120, n_waves=8, alpha=False)
+    assert status == 0 and ndef == 0
+    for i, s in enumerate(seqs):
+        a, b = int(offs[i]), int(offs[i + 1])
+        assert out2[a:b].tobytes() == want[i][0] and (int(strand2[i]), int(idx2[i])) == (want[i][1], want[i][2]), (i, len(s))
+
+
 @pytest.mark.parametrize("staged", [1, 3])
 def test_register_routine_with_n_mask(staged):
     """The streaming kernel's ALPHA build, bytes only: records of 48..1008 bases with a few N go through fast_canon's N-mask

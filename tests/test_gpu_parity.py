@@ -187,6 +187,53 @@ def test_team_mode_records_of_20_to_80_kb(ctx, O):
     ctx.use_own_stream()
 
 
+def test_four_bit_team_long_records_with_gaps_and_n_in_the_winning_window(ctx, O):
+    """What the 2-bit modes refuse and one wave's slice cannot hold in the 4-bit mode (beyond ~8 kb in stage A): gaps, an N inside
+    the winning window behind a prefix that other windows share.  The workgroup's waves take such a record as a team in the
+    4-bit mode (canon_core.h canon_record_team<4>: stage A up to ~41 kb, stage C ~80 kb, the team stage beyond) when the tiers
+    have real work -- the batch before said so -- and wave 0 alone otherwise: the same batch three times, all outputs through
+    the host API first."""
+    import torch
+    from tests import seqsets
+    rng = np.random.default_rng(2204)
+    comp = bytes.maketrans(b"ACGTN-", b"TGCAN-")
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    for L in [8200, 8704, 9000, 12287, 12288, 12289, 16384, 20000, 30000, 40900, 40928, 40929, 41000, 60000, 79000, 81000, 120000, 200000]:
+        s = bytearray(acgt[rng.integers(0, 4, L)].tobytes())
+        for p in rng.integers(0, L, size=L // 300):
+            s[int(p)] = ord("N")
+        s[int(rng.integers(0, L))] = ord("-")
+        seqs.append(bytes(s))
+    for case in range(60):                                       # near-ties of the prefix rule (tests/test_emu_kernel.py), 9..40 kb
+        L = int(rng.integers(9000, 40000))
+        bg = bytearray(np.frombuffer(b"CGT", dtype=np.uint8)[rng.choice(3, size=L, p=[0.2, 0.4, 0.4])].tobytes())
+        run = int(rng.integers(9, 14))
+        for sp in sorted(rng.choice(np.arange(20, L - 40, 30), size=int(rng.integers(2, 5)), replace=False)):
+            motif = b"A" * run + bytes(np.frombuffer(b"NGTCN", dtype=np.uint8)[rng.integers(0, 5, 1)]) + acgt[rng.integers(0, 4, 6)].tobytes()
+            if rng.random() < 0.5:
+                motif = motif.translate(comp)[::-1]
+            bg[int(sp):int(sp) + len(motif)] = motif
+        seqs.append(bytes(bg))
+    seqs = seqsets.random_mixed(93, 20, 200, 20000) + seqs + seqsets.random_mixed(94, 100, 48, 1008)
+    _check(ctx, O, seqs)
+    data, offs = seqsets.pack(seqs)
+    dev = torch.device("cuda", 0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d_bytes = torch.from_numpy(data).to(dev)
+    d_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    exp, exp_h = O.canonicalize_batch(data, offs, True, True, threads=8)
+    for k in range(3):
+        d_out = torch.zeros_like(d_bytes)
+        d_hash = torch.zeros(len(seqs), dtype=torch.int64, device=dev)
+        ctx.canonicalize_batch_device(d_bytes, d_off, len(seqs), out_bytes=d_out, out_xxh3=d_hash if k == 2 else None)
+        assert ctx.batch_status() == 0
+        assert np.array_equal(d_out.cpu().numpy(), exp)
+        if k == 2:
+            assert np.array_equal(d_hash.cpu().numpy().astype(np.uint64), exp_h)
+    ctx.use_own_stream()
+
+
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 257, 4095, 4096, 4097, 9000])
 def test_small_batch_segment_geometry(ctx, O, n):
     """Small batches get more list segments than the streaming kernel has workgroups with work, and the stages that walk

@@ -40,6 +40,9 @@ def main():
     if mixed:
         N = 1_000_000
         offs = W.log_uniform_offsets(N, 45)
+        if "--long" in sys.argv:                 # the tiers' own records: 20..80 kb (stage A: one wave up to 20.4 kb, its team beyond)
+            N = 40_000
+            offs = W.log_uniform_offsets(N, 45, 20000, 80000)
         total = int(offs[-1])
         d_off = offs.to(dev)
         d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
