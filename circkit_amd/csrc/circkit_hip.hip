@@ -1161,9 +1161,9 @@ __global__ __launch_bounds__(256) void uniq_keep_kernel(const uint64_t* __restri
 // record goes to ONE wave if it fits that wave's slice, to the workgroup's waves as a TEAM if it is 2-bit material and fits
 // their slices together, else to wave 0 ALONE with the workgroup's whole LDS (canon_core.h team_pass, canon_team_kernel).
 //   A: 4 waves x 5 KiB (7 workgroups per CU)      one wave: 2-bit up to ~20.4 kb (all of BASELINE config 4), few N ~13.6 kb,
-//                                                 4-bit ~8.2 kb (one stored strand since round 3); team: 2-bit ~81 kb, few N ~54 kb; alone: 4-bit ~33 kb
-//   C: 4 waves x 9.7 KiB (4 workgroups per CU)    team: 2-bit up to ~160 kb, few N ~106 kb; alone: 4-bit ~64 kb, bytes ~17 kb
-//   team stage: 16 waves x 157 KiB (the CU)       team: 2-bit up to ~640 kb, few N ~420 kb; alone: 4-bit ~250 kb, bytes ~70 kb
+//                                                 4-bit ~8.2 kb (one stored strand since round 3); team: 2-bit ~81 kb, few N ~54 kb, 4-bit ~41 kb; alone: 4-bit ~33 kb
+//   C: 4 waves x 9.7 KiB (4 workgroups per CU)    team: 2-bit up to ~160 kb, few N ~106 kb, 4-bit ~80 kb; alone: 4-bit ~64 kb, bytes ~17 kb
+//   team stage: 16 waves x 157 KiB (the CU)       team: 2-bit up to ~640 kb, few N ~420 kb, 4-bit ~320 kb; alone: 4-bit ~250 kb, bytes ~70 kb
 //   beyond: canon_global_kernel, the same over slices of a global-memory scratch (one more launch of every batch)
 // (One-wave slices of 7.4 / 13 / 39 / 157 KiB -- stages of their own in earlier versions -- remain for single-record calls.)
 #ifndef CK_RESCUE_BPC
