@@ -1031,12 +1031,16 @@ CK_DEV bool team_takes_2n(uint32_t n, uint32_t slice_dw, uint32_t team) { return
 CK_DEV uint32_t need_dw_strand4(uint32_t n) { return (n + 7) / 8 + 2; }
 CK_DEV bool team_takes_4(uint32_t n, uint32_t slice_dw, uint32_t team) { return n >= 48 && need_dw_strand4(n) <= team * slice_dw; }
 
-// List entries: bits 0..30 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
-// that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte).
-constexpr uint32_t ENTRY_NOT_ACGT = 0x80000000u, ENTRY_REC = 0x7FFFFFFFu;
+// List entries: bits 0..29 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
+// that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte), bit 30 (with
+// bit 31) = "the N-mask rule has had this record and refused it" -- the register routine's or the lean routine's N variant in the
+// kernel in front, canon_record_mode2n / the N-mask team in an earlier stage: the stages behind go straight to the 4-bit mode
+// (late round 4; before, stage A ran the N-mask mode again on every leftover of the N builds: build, two scans, the same refusal).
+constexpr uint32_t ENTRY_NOT_ACGT = 0x80000000u, ENTRY_NO_2N = 0x40000000u, ENTRY_REC = 0x3FFFFFFFu;
 
 // Processes one record; returns false if it does not fit this tier's LDS slice (not_acgt then says what was learnt).
-CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, bool& not_acgt)
+// no_2n: in -- skip the N-mask mode (it has refused this record before); out -- it has now
+CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, bool& not_acgt, bool& no_2n)
 {
     const uint64_t off = a.offsets[rec], len = a.offsets[rec + 1] - off;
     if (len >> 31) return false;                 // 32-bit cyclic positions (p < 2n): a record of 2 Gi symbols or more fits nowhere
@@ -1065,8 +1069,9 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
             }
         }
         // a few N: 2-bit words + an N bitmask (0 = done; else the 4-bit mode decides, here or in a bigger stage)
-        if (lutn && need_dw_2n(n) <= a.slice_dw) {
+        if (lutn && !no_2n && need_dw_2n(n) <= a.slice_dw) {
             if (canon_record_mode2n(a, rec, src, off, n, lds, lut, lutn) == 0) return true;
+            no_2n = true;
             wave_sync();            // every lane has read the strands before the next mode overwrites them
         }
         if (need_dw<4>(n) > a.slice_dw) return false;
@@ -1077,11 +1082,17 @@ CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const 
     return true;
 }
 
+CK_DEV bool canon_record(const CanonArgs& a, uint64_t rec, uint32_t* lds, const uint32_t* lut, const uint32_t* lutn, bool& not_acgt)
+{
+    bool no_2n = false;
+    return canon_record(a, rec, lds, lut, lutn, not_acgt, no_2n);
+}
+
 // append a record this launch cannot take to the workgroup's output segment (blk_count lives in LDS)
-CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block, uint32_t rec, bool not_acgt = false)
+CK_DEV void defer_record(const CanonArgs& a, uint32_t* blk_count, uint32_t block, uint32_t rec, bool not_acgt = false, bool no_2n = false)
 {
     if (lane_id() == 0) {
-        if (a.defer_list) a.defer_list[(uint64_t)block * a.out_seg_cap + lds_atomic_inc(blk_count)] = rec | (not_acgt ? ENTRY_NOT_ACGT : 0u);
+        if (a.defer_list) a.defer_list[(uint64_t)block * a.out_seg_cap + lds_atomic_inc(blk_count)] = rec | (not_acgt ? ENTRY_NOT_ACGT | (no_2n ? ENTRY_NO_2N : 0u) : 0u);
         else {
             // nothing can take this record (CIRCKIT_ERR_TOO_LONG through circkit_ctx_batch_status): a hash-only batch must not
             // find a stale view of an earlier batch in its place (out-of-bounds reads in the xxh3 pass)
@@ -1100,8 +1111,8 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
 {
     if (!a.list) {
         for (uint64_t rec = (uint64_t)block * wpb + wib; rec < a.n_records; rec += (uint64_t)nblocks * wpb) {
-            bool not_acgt = false;
-            if (!canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, (uint32_t)rec, not_acgt);
+            bool not_acgt = false, no_2n = false;
+            if (!canon_record(a, rec, lds, lut, lutn, not_acgt, no_2n)) defer_record(a, blk_count, block, (uint32_t)rec, not_acgt, no_2n);
             wave_sync();
         }
         return;
@@ -1111,8 +1122,8 @@ CK_DEV void canon_wave_loop(const CanonArgs& a, uint32_t* lds, const uint32_t* l
         const uint32_t* seg = a.list + (uint64_t)s * a.in_seg_cap;
         for (uint32_t i = wib; i < count; i += wpb) {
             const uint32_t rec = seg[i] & ENTRY_REC;
-            bool not_acgt = (seg[i] & ENTRY_NOT_ACGT) != 0;
-            if (!canon_record(a, rec, lds, lut, lutn, not_acgt)) defer_record(a, blk_count, block, rec, not_acgt);
+            bool not_acgt = (seg[i] & ENTRY_NOT_ACGT) != 0, no_2n = (seg[i] & ENTRY_NO_2N) != 0;
+            if (!canon_record(a, rec, lds, lut, lutn, not_acgt, no_2n)) defer_record(a, blk_count, block, rec, not_acgt, no_2n);
             wave_sync();
         }
     }
@@ -1129,7 +1140,8 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, co
     uint32_t* seg = a.defer_list + (uint64_t)block * a.out_seg_cap;
     uint32_t kept = 0;
     for (uint32_t k = 0; k < cnt; ++k) {
-        const uint32_t entry = seg[k], rec = entry & ENTRY_REC;      // written by this workgroup before the barrier
+        uint32_t entry = seg[k];                                     // written by this workgroup before the barrier
+        const uint32_t entry0 = entry, rec = entry & ENTRY_REC;
         bool done = false;
         const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
         if (len < (1ull << 31)) {
@@ -1137,7 +1149,10 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, co
             // the N-mask team has the next look); a flagged one holds an N, a gap or worse
             int why = (entry & ENTRY_NOT_ACGT) ? 1 : 3;            // 3: not tried
             if (why == 3 && team_takes((uint32_t)len, a.slice_dw, wpb)) { why = canon_record_team2(a, rec, lds, lut, blk_count + 1, wib, wpb); done = why == 0; }
-            if (why == 1 && lutn && team_takes_2n((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, wpb);
+            if (why == 1 && lutn && !(entry & ENTRY_NO_2N) && team_takes_2n((uint32_t)len, a.slice_dw, wpb)) {
+                done = canon_record_team2n(a, rec, lds, lut, lutn, blk_count + 1, wib, wpb);
+                entry |= ENTRY_NOT_ACGT | ENTRY_NO_2N;             // (if it stays on the list: the N-mask rule has had it)
+            }
             // what the N-mask team refuses (an N in the winning window behind a shared prefix), gaps: the 4-bit team
             if (team4 && !done && why == 1 && lutn && team_takes_4((uint32_t)len, a.slice_dw, wpb)) done = canon_record_team4(a, rec, lds, blk_count + 1, wib, wpb) == 0;
         }
@@ -1147,8 +1162,9 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, co
             CanonArgs solo = a;
             solo.slice_dw = wpb * a.slice_dw;
             if (wib == 0) {
-                bool na = (entry & ENTRY_NOT_ACGT) != 0;
-                const bool ok = canon_record(solo, rec, lds, lut, lutn, na);
+                bool na = (entry & ENTRY_NOT_ACGT) != 0, n2 = (entry & ENTRY_NO_2N) != 0;
+                const bool ok = canon_record(solo, rec, lds, lut, lutn, na, n2);
+                if (n2) entry |= ENTRY_NOT_ACGT | ENTRY_NO_2N;     // (wave 0 writes the list)
                 if (lane_id() == 0) blk_count[1] = ok ? 1u : 0u;
             }
             block_barrier();
@@ -1156,7 +1172,7 @@ CK_DEV void team_pass(const CanonArgs& a, uint32_t* lds, const uint32_t* lut, co
             block_barrier();
         }
         if (!done) {
-            if (wib == 0 && lane_id() == 0 && kept != k) seg[kept] = entry;
+            if (wib == 0 && lane_id() == 0 && (kept != k || entry != entry0)) seg[kept] = entry;
             ++kept;
         }
     }

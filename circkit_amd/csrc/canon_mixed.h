@@ -402,7 +402,8 @@ CK_DEV int lean_scan_locate(const uint32_t* E, const LeanGeom& g, LeanBest& bF, 
 }
 
 // One record of more than FAST_MAX_N symbols in the wave's slice.  0: done; 1: not this routine's alphabet (stage A is told);
-// 2: pure as far as seen, but a tie / equal strands / no room (stage A's general routine).
+// 2: pure as far as seen, but a tie / equal strands (stage A's general routine); 3: not tried -- no room in the slice, or (N build)
+// chunks outside the payload.
 #ifndef CK_LEAN_MIN_PREFIX
 #define CK_LEAN_MIN_PREFIX 6      // prefix rule: with fewer deciding symbols than this some other rotation shares them anyway (4^6 against ~10^4 rotations)
 #endif
@@ -420,11 +421,11 @@ CK_DEV int canon_lean_record(const CanonArgs& a, uint32_t rec, uint64_t off, uin
     // only; the N build leaves it to stage A.
     const bool inside = off >= g.a16 && off - g.a16 + 16ull * g.nW <= payload_end;
     if (!inside) {
-        if (NM) return 2;
+        if (NM) return 3;
         g.a16 = 0; g.T = n; g.nW = (n + 15) >> 4;
     }
     const uint32_t strand_dw = lean_strand_dw(n);
-    if (strand_dw + (NM ? lean_mask_dw(n) + LEAN_CAND_DW : 0) > a.slice_dw) return 2;
+    if (strand_dw + (NM ? lean_mask_dw(n) + LEAN_CAND_DW : 0) > a.slice_dw) return 3;
     uint32_t* E = slice + 1;
     // (NM: the N bits behind the strand, lean_resolve_n's candidate list in the slice's last LEAN_CAND_DW dwords)
     uint16_t* Mk = reinterpret_cast<uint16_t*>(slice + strand_dw) + 1;
@@ -622,9 +623,9 @@ CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint3
         const uint32_t rec = (uint32_t)first + i;
         const MixedNext cur = mixed_fetch(a, rec);
         const uint64_t off = cur.off, len = cur.len;
-        bool not_acgt = false, tried = false;
+        bool not_acgt = false, tried = false, ruled = false;      // ruled: the N-mask rule has had the record (entry bit 30)
         if (len >= FAST_MIN_N && len <= FAST_MAX_N) {
-            if constexpr (NM) { if (mixed_short_n<HASH>(a, lut, st, rec, cur, htab)) continue; tried = true; }
+            if constexpr (NM) { if (mixed_short_n<HASH>(a, lut, st, rec, cur, htab)) continue; tried = true; ruled = !HASH; }     // (builds with the XXH3: a short record with an N takes the 4-bit register routine, not the N-mask one)
             else { if (mixed_short<HASH>(a, lut, st, rec, cur, not_acgt, htab)) continue; }
         }
         // longer records -- and (pure build) the few short ones the register routine leaves (a tied minimal key, a minimal key
@@ -634,9 +635,10 @@ CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint3
             wave_sync();                                    // every lane is done with the slice before the next record's build
             if (r == 0) continue;
             not_acgt = NM || r == 1;
+            ruled = NM && r != 3;
         }
         not_acgt = not_acgt || tried;
-        defer_record(a, blk_count, sgm, rec, not_acgt);
+        defer_record(a, blk_count, sgm, rec, not_acgt, ruled);
     }
 }
 

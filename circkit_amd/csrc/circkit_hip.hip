@@ -114,19 +114,22 @@ __device__ __forceinline__ void team_stage_block(const ck::CanonArgs& a, uint32_
         for (uint32_t i = 0; i < count; ++i) {
             const uint32_t entry = seg[i], rec = entry & ck::ENTRY_REC;
             const uint64_t len = a.offsets[rec + 1] - a.offsets[rec];
-            bool done = false;
+            bool done = false, no_2n = (entry & ck::ENTRY_NO_2N) != 0;
             if (len >= 48 && len < (1ull << 31)) {
                 const uint32_t n = (uint32_t)len;
                 int why = (entry & ck::ENTRY_NOT_ACGT) ? 1 : 3;
                 if (why == 3 && ck::need_dw_strand2(n) <= total_dw) { why = ck::canon_record_team2(a, rec, buf, lut, blk_count + 1, wib, TEAM_WAVES); done = why == 0; }
-                if (why == 1 && ck::need_dw_2n(n) <= total_dw) done = ck::canon_record_team2n(a, rec, buf, lut, lutn, blk_count + 1, wib, TEAM_WAVES);
+                if (why == 1 && !(entry & ck::ENTRY_NO_2N) && ck::need_dw_2n(n) <= total_dw) {
+                    done = ck::canon_record_team2n(a, rec, buf, lut, lutn, blk_count + 1, wib, TEAM_WAVES);
+                    no_2n = true;
+                }
                 if (!done && why == 1 && ck::need_dw_strand4(n) <= total_dw) done = ck::canon_record_team4(a, rec, buf, blk_count + 1, wib, TEAM_WAVES) == 0;
             }
             if (!done) {
                 // not the team's: wave 0 alone with the same buffer, the general routine; the others wait
                 if (wib == 0) {
-                    bool not_acgt = (entry & ck::ENTRY_NOT_ACGT) != 0;
-                    if (!ck::canon_record(solo, rec, buf, lut, lutn, not_acgt)) ck::defer_record(a, blk_count, block, rec, not_acgt);
+                    bool not_acgt = (entry & ck::ENTRY_NOT_ACGT) != 0 || no_2n;
+                    if (!ck::canon_record(solo, rec, buf, lut, lutn, not_acgt, no_2n)) ck::defer_record(a, blk_count, block, rec, not_acgt, no_2n);
                 }
                 __syncthreads();
             }
@@ -1310,7 +1313,7 @@ int launch_canon(circkit_ctx* c, const uint8_t* d_bytes, const uint64_t* d_offse
 #ifdef CK_FORCE_HOST_MODE
     if (!host_mode) host_mode = CK_FORCE_HOST_MODE;      // experiment: no count kernel, no second build
 #endif
-    if (n >= (1ull << 31)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^31");
+    if (n >= (1ull << 30)) return fail(c, CIRCKIT_ERR_INVALID_ARG, "n_records must be < 2^30");      // (list entries: 30 bits of record index)
     CK_HIP(c, hipSetDevice(c->device));
     if (n == 0) { c->timed = false; return CIRCKIT_OK; }
     // MODE_GUESS.  Every mode computes the same results -- the mode only says which builds are the fast ones for the batch's

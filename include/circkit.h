@@ -73,7 +73,7 @@ int circkit_ctx_last_kernel_ms(circkit_ctx* ctx, float* ms);
  *                lmsr_index(revcomp(lmsr(s))) -- the two indices the reference computes (:43, :56)
  *   d_out_strand nullable; uint8[n_records]: 0 = lmsr(s) returned, 1 = lmsr(revcomp) returned (:58-62)
  *   d_out_xxh3   nullable; uint64[n_records]: XXH3-64 (seed 0) of the canonical sequence
- * n_records must be < 2^31 and every record shorter than 2^31 bytes.  No alignment or padding is required of
+ * n_records must be < 2^30 and every record shorter than 2^31 bytes.  No alignment or padding is required of
  * d_bytes / d_out_bytes, and offsets[0] need not be 0.
  * The call enqueues EVERYTHING the batch needs: once the stream has run past it the outputs are complete, whichever
  * way the caller synchronises, and the next batch may be enqueued straight behind it.  Records too long for the
