@@ -44,6 +44,8 @@ namespace {
 // + 1 % N: 2.068 -> 2.078 ms); as a __noinline__ call it takes the kernel from 72 to 87 registers.  So two builds: the one
 // without it for batches whose predecessor left the tiers next to nothing (launch_canon's tiers_idle; their few long records
 // with an N in the winning window go to wave 0 alone, as before round 4), the one with it for tiers that have real work.
+// (With the list entries' second flag bit the allocator's outcome for the build with it is 72 registers without spills as well --
+// an outcome five lines of unrelated code can change back: the two builds stay.)
 template <int WPB, bool T4 = false>
 __global__ __launch_bounds__(WPB * 64, CK_TIER_WPE) void canon_kernel(ck::CanonArgs a, uint32_t nvb, uint32_t* giants)
 {
