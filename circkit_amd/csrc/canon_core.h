@@ -1033,7 +1033,7 @@ CK_DEV bool team_takes_4(uint32_t n, uint32_t slice_dw, uint32_t team) { return 
 
 // List entries: bits 0..29 = record index, bit 31 = "holds a byte outside ACGT" (set by whichever stage found out, so
 // that the stages behind do not build the 2-bit strand of that record again just to stumble over the same byte), bit 30 (with
-// bit 31) = "the N-mask rule has had this record and refused it" -- the register routine's or the lean routine's N variant in the
+// bit 31) = "the N-mask rule, prefix rule included, has had this record and refused it" -- the lean routine's N variant in the
 // kernel in front, canon_record_mode2n / the N-mask team in an earlier stage: the stages behind go straight to the 4-bit mode
 // (late round 4; before, stage A ran the N-mask mode again on every leftover of the N builds: build, two scans, the same refusal).
 constexpr uint32_t ENTRY_NOT_ACGT = 0x80000000u, ENTRY_NO_2N = 0x40000000u, ENTRY_REC = 0x3FFFFFFFu;

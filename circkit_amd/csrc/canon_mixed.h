@@ -623,9 +623,11 @@ CK_DEV void canon_mixed_segment(const CanonArgs& a, uint32_t* slice, const uint3
         const uint32_t rec = (uint32_t)first + i;
         const MixedNext cur = mixed_fetch(a, rec);
         const uint64_t off = cur.off, len = cur.len;
-        bool not_acgt = false, tried = false, ruled = false;      // ruled: the N-mask rule has had the record (entry bit 30)
+        // ruled: the N-mask rule with its prefix rule has had the record (entry bit 30) -- the lean routine's; NOT the register
+        // routine's N variant, which refuses every N among the deciding symbols where the tiers' N-mask mode may still succeed
+        bool not_acgt = false, tried = false, ruled = false;
         if (len >= FAST_MIN_N && len <= FAST_MAX_N) {
-            if constexpr (NM) { if (mixed_short_n<HASH>(a, lut, st, rec, cur, htab)) continue; tried = true; ruled = !HASH; }     // (builds with the XXH3: a short record with an N takes the 4-bit register routine, not the N-mask one)
+            if constexpr (NM) { if (mixed_short_n<HASH>(a, lut, st, rec, cur, htab)) continue; tried = true; }
             else { if (mixed_short<HASH>(a, lut, st, rec, cur, not_acgt, htab)) continue; }
         }
         // longer records -- and (pure build) the few short ones the register routine leaves (a tied minimal key, a minimal key

@@ -276,7 +276,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
             const uint64_t off = k ? o1 : o0;                           // (o2 is loaded but unused when RPW == 1)
             const uint32_t n = (uint32_t)(k ? o2 : o1) - (uint32_t)off;
             const uint32_t rec = ra + k;
-            bool done = false, tried4 = false, ruled = false;      // ruled: the N-mask variant has had the record (list entry bit 30)
+            bool done = false, tried4 = false;
             if (C::ROWS == 2 && q[0].ok && fast2_eligible(n)) {
                 // 1009..2032 bases: two chunks per lane (c0 + 2t, c0 + 2t + 1); the word behind them is lane t+1's first
                 const uint32_t rel = (uint32_t)off - q[0].base_lo, a16 = rel & 15, nch = (a16 + n + 15) >> 4;     // <= 128
@@ -320,7 +320,7 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
                         // (with the XXH3 every record of the build leaves its last stripe as bytes -- the merger is built for that --, so
                         // the few without an N take the N-mask variant with an empty mask)
                         if (!HASH && with_n == 0) done = fast_canon<HASH, false, GH, true, false, true>(a, lut, hc, shape, rec, off, n, Fw, 0, slot);
-                        else { done = fast_canon<HASH, false, GH, true, true, true>(a, lut, hc, shape, rec, off, n, Fw, 0, slot, lshr64(nm, wave_shl1(nm), 32 - 2 * a16)); ruled = true; }
+                        else done = fast_canon<HASH, false, GH, true, true, true>(a, lut, hc, shape, rec, off, n, Fw, 0, slot, lshr64(nm, wave_shl1(nm), 32 - 2 * a16));
                     }
                     bad |= with_n;                  // (what the 4-bit routine is for)
                 } else {
@@ -344,7 +344,10 @@ CK_DEV void canon_stream_wave_loop(const CanonArgs& a, const uint32_t* lut, uint
             // The entry's flag: the 4-bit register routine has had this record (a tied 8-symbol key, mostly) -- the rescue
             // pass, which would run the same routine again, hands it on.  (Otherwise no alphabet flag: the edge chunks hold
             // neighbours' bytes too.  A flagged record that is pure ACGT itself takes the N-mask mode of the tiers: correct.)
-            if (!done) defer_record(a, blk_count, block, rec, ALPHA && tried4, ruled);
+            // (Not the entries' second flag: the register routine's N variant refuses every N among the deciding symbols, the
+            // tiers' N-mask mode has the prefix rule for them and may still succeed.  Setting it here as well measured the same
+            // on 1 % and 10 % N, fixed and mixed lengths: tools/ruled_ab.sh.)
+            if (!done) defer_record(a, blk_count, block, rec, ALPHA && tried4);
         }
         // the previous group's hashes: its slots were complete at the barrier that ended the previous iteration
         if constexpr (GH) {
